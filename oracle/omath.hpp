@@ -45,6 +45,9 @@ inline float dot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 inline float sqnorm(V3 a) { return dot(a, a); }
 inline float norm(V3 a) { return std::sqrt(sqnorm(a)); }
 inline V3 normalized(V3 a) { float n = norm(a); return a / n; }                  // Dot.h:114-120: n / n.norm()
+// Reductions over DYNAMIC-size Eigen expressions (anything built directly on m_N.col(i) / m_V.col(i) blocks,
+// e.g. src/mesh.cpp:69-73,154-157) are not unrolled: Redux.h falls back to the sequential loop (x0+x1)+x2.
+inline V3 normalized_seq(V3 a) { float n = std::sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); return a / n; }
 inline V3 cross(V3 a, V3 b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }

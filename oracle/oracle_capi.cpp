@@ -203,3 +203,17 @@ void orc_bsdf_sample(int type, const float *params, int n, const float *wi, cons
 void orc_nl_means(const float *img, float *out, int w, int h, int r, int f, float sigma, float hh) { nl_means(img, out, w, h, r, f, sigma, hh); }
 
 } // extern "C"
+
+extern "C" {
+// Li for explicit rays: sample i uses pcg32.seed(states[i], seqs[i]), skips the 4 camera draws, then runs Li.
+void orc_li_rays(void *hp, int si, int n, const float *rays, const uint64_t *states, const uint64_t *seqs, float *rgb) {
+    const Scene *sc; const Accel *ac; sub(hp, si, &sc, &ac);
+    for (int i = 0; i < n; ++i) {
+        Sampler s; s.rng.seed(states[i], seqs[i]); (void) s.next2D(); (void) s.next2D();
+        const float *q = rays + 8 * (size_t) i;
+        Ray r; r.o = mk3(q[0], q[1], q[2]); r.mint = q[3]; r.d = mk3(q[4], q[5], q[6]); r.maxt = q[7]; r.update();
+        V3 v = path_mis_li(*ac, s, r);
+        rgb[3 * i] = v.x; rgb[3 * i + 1] = v.y; rgb[3 * i + 2] = v.z;
+    }
+}
+}

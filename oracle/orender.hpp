@@ -147,7 +147,7 @@ struct Accel {
         }
         its.geo = Frame(normalized(cross(p1 - p0, p2 - p0)));
         if (!m.N.empty()) {
-            V3 n = normalized((b0 * m.N[i0] + b1 * m.N[i1]) + b2 * m.N[i2]);
+            V3 n = normalized_seq((b0 * m.N[i0] + b1 * m.N[i1]) + b2 * m.N[i2]);
             its.sh = Frame(n);
         } else its.sh = its.geo;
     }
@@ -348,7 +348,7 @@ inline void shape_sample_surface(const Shape &m, V2 sample, V3 &p, V3 &n, float 
     V3 bc = square_to_uniform_triangle(s);
     uint32_t i0 = m.F[3 * idT], i1 = m.F[3 * idT + 1], i2 = m.F[3 * idT + 2];
     p = (bc.x * m.V[i0] + bc.y * m.V[i1]) + bc.z * m.V[i2];
-    if (!m.N.empty()) n = normalized((bc.x * m.N[i0] + bc.y * m.N[i1]) + bc.z * m.N[i2]);
+    if (!m.N.empty()) n = normalized_seq((bc.x * m.N[i0] + bc.y * m.N[i1]) + bc.z * m.N[i2]);
     else n = normalized(cross(m.V[i1] - m.V[i0], m.V[i2] - m.V[i0]));
     pdf = m.cdf_norm;
 }
