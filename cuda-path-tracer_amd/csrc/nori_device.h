@@ -1,0 +1,530 @@
+// Device-side restatement of Nori's per-ray arithmetic for gfx950.
+//
+// Everything that feeds an integer-exact comparison (camera rays, slab test, Moller-Trumbore, sphere test,
+// hit reconstruction) keeps the reference's operation ORDER and is compiled without FMA contraction, so that
+// primary-hit primitive ids are bit-identical to the CPU renderer's (DESIGN.md "float parity").
+// Reference: include/nori/{frame,bbox,ray}.h, src/common.cpp:274-314, src/mesh.cpp:84-168, src/sphere.cpp:42-141,
+//            src/warp.cpp, src/{diffuse,microfacet,dielectric,mirror,arealight}.cpp, src/pathMisIntegrator.cpp,
+//            ext/pcg32/pcg32.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nori_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace nd {
+
+#define ND_INF __builtin_huge_valf()
+#define ND_PI 3.14159265358979323846f       /* include/nori/common.h:56 — a float literal in the reference */
+#define ND_INV_PI 0.31830988618379067154f
+#define ND_EPS 1e-4f
+
+struct F3 { float x, y, z; };
+struct F2 { float x, y; };
+
+__device__ __forceinline__ F3 f3(float a, float b, float c) { F3 r; r.x = a; r.y = b; r.z = c; return r; }
+__device__ __forceinline__ F3 f3(float a) { return f3(a, a, a); }
+__device__ __forceinline__ F3 f3(const float *p) { return f3(p[0], p[1], p[2]); }
+__device__ __forceinline__ F2 f2(float a, float b) { F2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return f3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator/(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+// Eigen's unrolled 3-term reduction: x0 + (x1 + x2)
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ float norm(F3 a) { return __fsqrt_rn(dot(a, a)); }
+__device__ __forceinline__ F3 normalized(F3 a) { float n = norm(a); return a / n; }
+// reductions over dynamic-size Eigen expressions are sequential (src/mesh.cpp:69-73,154-157)
+__device__ __forceinline__ F3 normalized_seq(F3 a) { float n = __fsqrt_rn((a.x * a.x + a.y * a.y) + a.z * a.z); return a / n; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ bool is_zero(F3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
+__device__ __forceinline__ bool color_valid(F3 c) {      // Color3f::isValid, src/common.cpp:224-231
+    return !(c.x < 0 || !isfinite(c.x) || c.y < 0 || !isfinite(c.y) || c.z < 0 || !isfinite(c.z));
+}
+
+// src/common.cpp:274-283, include/nori/frame.h:49-63
+struct Frame {
+    F3 s, t, n;
+    __device__ __forceinline__ void set(F3 a) {
+        n = a; F3 c;
+        if (fabsf(a.x) > fabsf(a.y)) { float invLen = 1.0f / __fsqrt_rn(a.x * a.x + a.z * a.z); c = f3(a.z * invLen, 0.0f, -a.x * invLen); }
+        else { float invLen = 1.0f / __fsqrt_rn(a.y * a.y + a.z * a.z); c = f3(0.0f, a.z * invLen, -a.y * invLen); }
+        t = c; s = cross(c, a);
+    }
+    __device__ __forceinline__ F3 toLocal(F3 v) const { return f3(dot(v, s), dot(v, t), dot(v, n)); }
+    __device__ __forceinline__ F3 toWorld(F3 v) const { return (s * v.x + t * v.y) + n * v.z; }
+};
+
+// ext/pcg32/pcg32.h:51-66,101-110
+struct Pcg32 {
+    uint64_t state, inc;
+    __device__ __forceinline__ uint32_t next_uint() {
+        uint64_t old = state;
+        state = old * 0x5851f42d4c957f2dULL + inc;
+        uint32_t xorshifted = (uint32_t) (((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t) (old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31));
+    }
+    __device__ __forceinline__ void seed(uint64_t initstate, uint64_t initseq) {
+        state = 0U; inc = (initseq << 1u) | 1u; next_uint(); state += initstate; next_uint();
+    }
+    __device__ __forceinline__ float next1D() { return __uint_as_float((next_uint() >> 9) | 0x3f800000u) - 1.0f; }
+    // Independent::next2D (src/independent.cpp:62-67): the reference's compiler evaluates the second constructor
+    // argument first, so y receives the earlier draw (pinned in oracle/make_golden.py).
+    __device__ __forceinline__ F2 next2D() { float a = next1D(); float b = next1D(); return f2(b, a); }
+};
+
+struct DevScene {
+    const NoriHipNode *nodes;
+    const float4 *prims;               // 3 x float4 per NoriHipPrim
+    const NoriHipShadePrim *shade;
+    const NoriHipShape *shapes;
+    const NoriHipEmitter *emitters;
+    const float *cdf;
+    const NoriHipShadePrim *light_prims;
+    uint32_t root, n_emitters;
+    float root_min[3], root_max[3];
+    NoriHipCamera cam;
+    float inv_w, inv_h;
+    int border, film_cols;
+};
+
+struct Ray { F3 o, d; float mint, maxt; };
+struct Hit { uint32_t pos; float t, u, v; };       // pos = record index in leaf order; 0xffffffff = miss
+
+// include/nori/bbox.h:336-363.  `near_out` is the entry distance; the caller re-checks it against a shrunken
+// maxt when the node is popped, which is exactly what re-running the reference's test then would decide.
+__device__ __forceinline__ bool slab(const float *bmin, const float *bmax, F3 o, F3 d, F3 rcp, float mint, float maxt, float &near_out) {
+    float nearT = -ND_INF, farT = ND_INF;
+    {
+        if (d.x == 0) { if (o.x < bmin[0] || o.x > bmax[0]) return false; }
+        else { float t1 = (bmin[0] - o.x) * rcp.x, t2 = (bmax[0] - o.x) * rcp.x; if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+               nearT = (t1 < nearT) ? nearT : t1; farT = (farT < t2) ? farT : t2; if (!(nearT <= farT)) return false; }
+    }
+    {
+        if (d.y == 0) { if (o.y < bmin[1] || o.y > bmax[1]) return false; }
+        else { float t1 = (bmin[1] - o.y) * rcp.y, t2 = (bmax[1] - o.y) * rcp.y; if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+               nearT = (t1 < nearT) ? nearT : t1; farT = (farT < t2) ? farT : t2; if (!(nearT <= farT)) return false; }
+    }
+    {
+        if (d.z == 0) { if (o.z < bmin[2] || o.z > bmax[2]) return false; }
+        else { float t1 = (bmin[2] - o.z) * rcp.z, t2 = (bmax[2] - o.z) * rcp.z; if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+               nearT = (t1 < nearT) ? nearT : t1; farT = (farT < t2) ? farT : t2; if (!(nearT <= farT)) return false; }
+    }
+    near_out = nearT;
+    return mint <= farT && nearT <= maxt;
+}
+
+#ifndef ND_STACK
+#define ND_STACK 64        /* the reference's traversal stack holds 64 entries (src/bvh.cpp:405) */
+#endif
+
+// BVH::rayIntersect (src/bvh.cpp:404-463) over 64-byte two-box nodes, in the reference's visiting order
+// (left subtree first, right pushed), so closest-hit ties resolve to the same primitive.
+// Stack entries are (child reference, entry distance); `stk` may live in LDS or scratch.
+template <bool ANY, typename StackT>
+__device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
+    F3 o = ray_in.o, d = ray_in.d;
+    float mint = ray_in.mint, maxt = ray_in.maxt;
+    hit.pos = 0xffffffffu; hit.t = ND_INF; hit.u = hit.v = 0.f;
+    if (mint == ND_EPS) {                       // adaptive epsilon, src/bvh.cpp:411-412
+        float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+        float e = mint * m; mint = (mint < e) ? e : mint;
+    }
+    if (maxt < mint) return false;
+    F3 rcp = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float nr;
+    n_nodes++;
+    if (!slab(sc.root_min, sc.root_max, o, d, rcp, mint, maxt, nr)) return false;
+    uint32_t cur = sc.root;
+    int sp = 0;
+    bool found = false;
+    for (;;) {
+        if (cur & NORI_HIP_LEAF_BIT) {
+            uint32_t pos = cur & 0x7fffffffu;
+            uint32_t flags;
+            do {
+                const float4 *r = sc.prims + 3 * (size_t) pos;
+                float4 A = r[0], B = r[1], C = r[2];
+                flags = __float_as_uint(C.z);
+                n_prims++;
+                float t = 0.f, u = 0.f, v = 0.f; bool h = false;
+                if (!(flags & 0x40000000u)) {
+                    // Mesh::rayIntersect, src/mesh.cpp:84-121
+                    F3 p0 = f3(A.x, A.y, A.z), edge1 = f3(A.w, B.x, B.y), edge2 = f3(B.z, B.w, C.x);
+                    F3 pvec = cross(d, edge2);
+                    float det = dot(edge1, pvec);
+                    if (!(det > -1e-8f && det < 1e-8f)) {
+                        float inv_det = 1.0f / det;
+                        F3 tvec = o - p0;
+                        u = dot(tvec, pvec) * inv_det;
+                        if (!(u < 0.0f || u > 1.0f)) {
+                            F3 qvec = cross(tvec, edge1);
+                            v = dot(d, qvec) * inv_det;
+                            if (!(v < 0.0f || u + v > 1.0f)) {
+                                t = dot(edge2, qvec) * inv_det;
+                                h = t >= mint && t <= maxt;
+                            }
+                        }
+                    }
+                } else {
+                    // Sphere::rayIntersect, src/sphere.cpp:42-113
+                    F3 c = f3(A.x, A.y, A.z); float rad = A.w;
+                    float Bq = 2 * dot(o - c, d);
+                    float Cq = ((-rad * rad + dot(c, c)) + dot(o, o)) - 2 * dot(c, o);
+                    float discr = Bq * Bq - 4 * Cq;
+                    if (discr > 0) {
+                        float sq = __fsqrt_rn(discr);
+                        float t1 = (-Bq + sq) * 0.5f, t2 = (-Bq - sq) * 0.5f;
+                        bool v1 = t1 >= mint && t1 <= maxt, v2 = t2 >= mint && t2 <= maxt;
+                        if (v1 && v2) { t = (t2 < t1) ? t2 : t1; h = true; }
+                        else if (v1) { t = t1; h = true; }
+                        else if (v2) { t = t2; h = true; }
+                    } else if (discr == 0) {
+                        float tt = -Bq * 0.5f;
+                        if (tt >= mint && tt < maxt) { t = tt; h = true; }
+                    }
+                }
+                if (h) {
+                    if (ANY) return true;
+                    found = true; maxt = t; hit.pos = pos; hit.t = t; hit.u = u; hit.v = v;
+                }
+                pos++;
+            } while (!(flags & 0x80000000u));
+            // pop: an entry is skipped when its box no longer passes with the current maxt
+            bool got = false;
+            while (sp > 0) { uint2 e = stk.pop(--sp); if (__uint_as_float(e.y) <= maxt) { cur = e.x; got = true; break; } }
+            if (!got) break;
+        } else {
+            const float4 *q = reinterpret_cast<const float4 *>(sc.nodes + cur);
+            float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+            uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+            float nl, nrr;
+            n_nodes += 2;
+            bool hl = slab(lmin, lmax, o, d, rcp, mint, maxt, nl);
+            bool hr = (right != NORI_HIP_NO_CHILD) && slab(rmin, rmax, o, d, rcp, mint, maxt, nrr);
+            if (hl) { if (hr) { stk.push(sp++, make_uint2(right, __float_as_uint(nrr))); } cur = left; }
+            else if (hr) cur = right;
+            else {
+                bool got = false;
+                while (sp > 0) { uint2 e = stk.pop(--sp); if (__uint_as_float(e.y) <= maxt) { cur = e.x; got = true; break; } }
+                if (!got) break;
+            }
+        }
+    }
+    return found;
+}
+
+// per-lane stack in private (scratch) memory
+struct ScratchStack {
+    uint2 e[ND_STACK];
+    __device__ __forceinline__ void push(int i, uint2 v) { e[i] = v; }
+    __device__ __forceinline__ uint2 pop(int i) const { return e[i]; }
+};
+
+struct Surface { F3 p; F2 uv; Frame sh; F3 geo_n; uint32_t shape; uint32_t prim; };
+
+// Mesh::setHitInformation (src/mesh.cpp:123-168) / Sphere::setHitInformation (src/sphere.cpp:115-141)
+__device__ __forceinline__ void surface_from_hit(const DevScene &sc, const Ray &ray, const Hit &hit, Surface &s, bool want_geo) {
+    const float4 *r = sc.prims + 3 * (size_t) hit.pos;
+    float4 C = r[2];
+    uint32_t flags = __float_as_uint(C.z);
+    s.shape = flags & 0xffffffu; s.prim = __float_as_uint(C.y);
+    const NoriHipShape &shp = sc.shapes[s.shape];
+    if (flags & 0x40000000u) {
+        F3 c = f3(shp.center);
+        s.p = ray.o + hit.t * ray.d;
+        F3 n = normalized(s.p - c);
+        s.sh.set(n); s.geo_n = n;
+        F3 pl = s.p - c;
+        float frac = pl.z / shp.radius;
+        if (frac < -1) frac = -1; else if (frac > 1) frac = 1;
+        float theta = acosf(frac) / ND_PI;
+        float phi = (atan2f(pl.y, pl.x) + ND_PI) / (2 * ND_PI);
+        s.uv = f2(phi, theta);
+        return;
+    }
+    const NoriHipShadePrim &sp = sc.shade[hit.pos];
+    float b0 = 1 - (hit.u + hit.v), b1 = hit.u, b2 = hit.v;
+    F3 p0 = f3(sp.p0), p1 = f3(sp.p1), p2 = f3(sp.p2);
+    s.p = (b0 * p0 + b1 * p1) + b2 * p2;
+    if (shp.flags & 2u) s.uv = f2((b0 * sp.uv0[0] + b1 * sp.uv1[0]) + b2 * sp.uv2[0], (b0 * sp.uv0[1] + b1 * sp.uv1[1]) + b2 * sp.uv2[1]);
+    else s.uv = f2(hit.u, hit.v);
+    if (shp.flags & 1u) {
+        F3 n = normalized_seq((b0 * f3(sp.n0) + b1 * f3(sp.n1)) + b2 * f3(sp.n2));
+        s.sh.set(n);
+        if (want_geo) s.geo_n = normalized(cross(p1 - p0, p2 - p0));
+    } else {
+        F3 g = normalized(cross(p1 - p0, p2 - p0));
+        s.sh.set(g); s.geo_n = g;
+    }
+}
+
+// PerspectiveCamera::sampleRay (src/perspective.cpp:90-111); Transform::operator* (include/nori/transform.h:68-81)
+__device__ __forceinline__ F3 xform_point(const float *m, F3 p) {
+    float r0 = ((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3] * 1.0f;
+    float r1 = ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7] * 1.0f;
+    float r2 = ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11] * 1.0f;
+    float r3 = ((m[12] * p.x + m[13] * p.y) + m[14] * p.z) + m[15] * 1.0f;
+    return f3(r0 / r3, r1 / r3, r2 / r3);
+}
+__device__ __forceinline__ F3 xform_vector(const float *m, F3 v) {
+    return f3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z, (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
+}
+__device__ __forceinline__ void camera_ray(const DevScene &sc, F2 ps, Ray &ray) {
+    F3 nearP = xform_point(sc.cam.sample_to_camera, f3(ps.x * sc.inv_w, ps.y * sc.inv_h, 0.0f));
+    F3 d = normalized(nearP);
+    float invZ = 1.0f / d.z;
+    ray.o = xform_point(sc.cam.camera_to_world, f3(0.f, 0.f, 0.f));
+    ray.d = xform_vector(sc.cam.camera_to_world, d);
+    ray.mint = sc.cam.near_clip * invZ;
+    ray.maxt = sc.cam.far_clip * invZ;
+}
+
+// ---- warps (src/warp.cpp:59-63,221-244,263-267) ----------------------------------------------------------
+__device__ __forceinline__ F3 square_to_cosine_hemisphere(F2 s) {
+    float r = __fsqrt_rn(s.x);
+    float theta = 2 * ND_PI * s.y;
+    float sn, cs; sincosf(theta, &sn, &cs);
+    float dx = r * cs, dy = r * sn;
+    return f3(dx, dy, __fsqrt_rn(1.0f - dx * dx - dy * dy));
+}
+__device__ __forceinline__ F3 square_to_beckmann(F2 s, float alpha) {
+    float inner = 1.0f / (1.0f - alpha * alpha * logf(1.0f - s.x));
+    float theta = acosf(__fsqrt_rn(inner));
+    float phi = s.y * 2.0f * ND_PI;
+    float st, ct, sp, cp; sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+    return f3(st * cp, st * sp, ct);
+}
+__device__ __forceinline__ F3 square_to_uniform_triangle(F2 s) {
+    float su1 = __fsqrt_rn(s.x);
+    float u = 1.f - su1, v = s.y * su1;
+    return f3(u, v, 1.f - u - v);
+}
+
+// src/common.cpp:285-314
+__device__ __forceinline__ float fresnel(float cosThetaI, float extIOR, float intIOR) {
+    float etaI = extIOR, etaT = intIOR;
+    if (extIOR == intIOR) return 0.0f;
+    if (cosThetaI < 0.0f) { float s = etaI; etaI = etaT; etaT = s; cosThetaI = -cosThetaI; }
+    float eta = etaI / etaT, sinThetaTSqr = eta * eta * (1 - cosThetaI * cosThetaI);
+    if (sinThetaTSqr > 1.0f) return 1.0f;
+    float cosThetaT = __fsqrt_rn(1.0f - sinThetaTSqr);
+    float Rs = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
+    float Rp = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
+    return (Rs * Rs + Rp * Rp) / 2.0f;
+}
+__device__ __forceinline__ float tan_theta(F3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return __fsqrt_rn(temp) / v.z; }
+
+// ---- BSDFs ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float beckmann_D(float alpha, F3 m) {          // src/microfacet.cpp:55-61
+    float temp = tan_theta(m) / alpha, ct = m.z, ct2 = ct * ct;
+    return expf(-temp * temp) / (ND_PI * alpha * alpha * ct2 * ct2);
+}
+__device__ __forceinline__ float smith_g1(float alpha, F3 v, F3 m) {      // src/microfacet.cpp:64-84
+    float tanTheta = tan_theta(v);
+    if (tanTheta == 0.0f) return 1.0f;
+    if (dot(m, v) * v.z <= 0) return 0.0f;
+    float a = 1.0f / (alpha * tanTheta);
+    if (a >= 1.6f) return 1.0f;
+    float a2 = a * a;
+    return (3.535f * a + 2.181f * a2) / (1.0f + 2.276f * a + 2.577f * a2);
+}
+__device__ __forceinline__ F3 bsdf_eval(const NoriHipShape &b, F3 wi, F3 wo) {
+    if (b.bsdf == NORI_HIP_BSDF_DIFFUSE) {                                // src/diffuse.cpp:75-86
+        if (wi.z <= 0 || wo.z <= 0) return f3(0.f);
+        return f3(b.albedo) * ND_INV_PI;
+    }
+    if (b.bsdf == NORI_HIP_BSDF_MICROFACET) {                             // src/microfacet.cpp:87-100
+        F3 wh = normalized(wi + wo);
+        float G = smith_g1(b.alpha, wi, wh) * smith_g1(b.alpha, wo, wh);
+        float ci = wi.z, co = wo.z;
+        if (co > 0 && ci > 0) {
+            float spec = (b.ks * beckmann_D(b.alpha, wh) * fresnel(dot(wh, wi), b.ext_ior, b.int_ior) * G) / (4 * ci * co);
+            return f3(b.albedo) / ND_PI + f3(spec);
+        }
+        return f3(0.f);
+    }
+    return f3(0.f);
+}
+__device__ __forceinline__ float bsdf_pdf(const NoriHipShape &b, F3 wi, F3 wo) {
+    if (b.bsdf == NORI_HIP_BSDF_DIFFUSE) {                                // src/diffuse.cpp:89-105
+        if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+        return ND_INV_PI * wo.z;
+    }
+    if (b.bsdf == NORI_HIP_BSDF_MICROFACET) {                             // src/microfacet.cpp:103-117
+        F3 wh = normalized(wi + wo);
+        float ch = wh.z, co = wo.z, ci = wi.z;
+        float Jh = 1.0f / (4 * dot(wh, wo));
+        if (co > 0 && ci > 0) return b.ks * beckmann_D(b.alpha, wh) * ch * Jh + (1 - b.ks) * co / ND_PI;
+        return 0.f;
+    }
+    return 0.0f;
+}
+// returns the importance weight; wo_valid=false marks the reference's early returns that leave wo unset
+__device__ __forceinline__ F3 bsdf_sample(const NoriHipShape &b, F3 wi, F2 sample, F3 &wo, bool &is_delta, bool &wo_valid) {
+    wo_valid = true; is_delta = false; wo = f3(0.f);
+    switch (b.bsdf) {
+    case NORI_HIP_BSDF_DIFFUSE:                                           // src/diffuse.cpp:109-126
+        if (wi.z <= 0) { wo_valid = false; return f3(0.f); }
+        wo = square_to_cosine_hemisphere(sample);
+        return f3(b.albedo);
+    case NORI_HIP_BSDF_MICROFACET: {                                      // src/microfacet.cpp:121-161
+        if (sample.x < b.ks) {
+            sample.x /= b.ks;
+            F3 wh = square_to_beckmann(sample, b.alpha);
+            wh = wh / norm(wh);
+            wo = -wi + (2 * dot(wh, wi)) * wh;
+            if (wo.z <= 0) return f3(0.f);
+        } else {
+            sample.x = (sample.x - b.ks) / (1.0f - b.ks);
+            wo = square_to_cosine_hemisphere(sample);
+        }
+        float co = wo.z;
+        if (co > 0) {
+            float pdf_val = bsdf_pdf(b, wi, wo);
+            if (fabsf(pdf_val) > 1e-6) return (bsdf_eval(b, wi, wo) * co) / pdf_val;
+        }
+        return f3(0.f);
+    }
+    case NORI_HIP_BSDF_DIELECTRIC: {                                      // src/dielectric.cpp:48-103
+        float ci = wi.z;
+        float extIOR = b.ext_ior, intIOR = b.int_ior;
+        if (ci < 0) { extIOR = b.int_ior; intIOR = b.ext_ior; }
+        float F = fresnel(fabsf(ci), extIOR, intIOR);
+        is_delta = true;
+        if (sample.x <= F) { wo = f3(-wi.x, -wi.y, wi.z); return f3(1.0f); }
+        F3 n = f3(0, 0, 1.0f); if (ci < 0) n = f3(0, 0, -1.0f);
+        float win = dot(wi, n);
+        float IORrel = extIOR / intIOR;
+        float root = (float) sqrt(1.0 - (double) (IORrel * IORrel) * (1.0 - (double) (win * win)));   // double in the reference
+        F3 w = (-IORrel) * (wi - win * n) - n * root;
+        wo = w / norm(w);
+        float inv = 1.0f / IORrel;
+        return f3(inv * inv);
+    }
+    default:                                                              // mirror, src/mirror.cpp:41-58
+        if (wi.z <= 0) { wo_valid = false; return f3(0.f); }
+        wo = f3(-wi.x, -wi.y, wi.z); is_delta = true;
+        return f3(1.0f);
+    }
+}
+
+// ---- area emitter (src/arealight.cpp:41-116, src/mesh.cpp:40-61, include/nori/dpdf.h:119-157) -------------
+__device__ __forceinline__ float emitter_pdf(float area_pdf, F3 ref, F3 p, F3 n, F3 wi) {
+    F3 dd = ref - p; float dist2 = dot(dd, dd);
+    float costheta = -dot(normalized(wi), normalized(n));
+    if (costheta <= 0) return 0.0f;
+    return area_pdf * dist2 / fabsf(costheta);
+}
+__device__ __forceinline__ float shape_area_pdf(const DevScene &sc, const NoriHipShape &shp) {
+    if (shp.type == NORI_HIP_SHAPE_SPHERE) { float a = 1.f / shp.radius; return (a * a) * (1.0f / (4.0f * ND_PI)); }   // src/sphere.cpp:150-152
+    return sc.emitters[shp.emitter].area_pdf;
+}
+// Emitter::sample: fills p, n, wi, shadow ray (from the light to ref), returns radiance / pdf
+__device__ __forceinline__ F3 emitter_sample(const DevScene &sc, const NoriHipEmitter &em, F3 ref, F2 sample, F3 &wi, F3 &ln, F3 &lp, Ray &shadow) {
+    const NoriHipShape &shp = sc.shapes[em.shape];
+    F3 p, n; float apdf;
+    if (shp.type == NORI_HIP_SHAPE_SPHERE) {                              // src/sphere.cpp:143-149, src/warp.cpp:26-31,198-203
+        float phi = 2 * ND_PI * sample.x, sn, cs; sincosf(phi, &sn, &cs);
+        float z = 2.0f * sample.y - 1.0f; float r = __fsqrt_rn(1.0f - (z * z));
+        F3 q = f3(cs * r, sn * r, z);
+        p = f3(shp.center) + shp.radius * q; n = q;
+        apdf = (float) (1.0 / (4.0 * ND_PI * shp.radius * shp.radius));
+    } else {
+        const float *cdf = sc.cdf + em.cdf_offset;
+        // std::lower_bound over n_tris+1 entries, then DiscretePDF::sample's clamps
+        uint32_t lo = 0, len = em.n_tris + 1;
+        while (len > 0) { uint32_t half = len >> 1; if (cdf[lo + half] < sample.x) { lo += half + 1; len -= half + 1; } else len = half; }
+        int idx = (int) lo - 1; if (idx < 0) idx = 0; if (idx > (int) em.n_tris - 1) idx = (int) em.n_tris - 1;
+        float sx = (sample.x - cdf[idx]) / (cdf[idx + 1] - cdf[idx]);
+        F3 bc = square_to_uniform_triangle(f2(sx, sample.y));
+        const NoriHipShadePrim &lt = sc.light_prims[em.light_prim_offset + idx];
+        F3 p0 = f3(lt.p0), p1 = f3(lt.p1), p2 = f3(lt.p2);
+        p = (bc.x * p0 + bc.y * p1) + bc.z * p2;
+        if (shp.flags & 1u) n = normalized_seq((bc.x * f3(lt.n0) + bc.y * f3(lt.n1)) + bc.z * f3(lt.n2));
+        else n = normalized(cross(p1 - p0, p2 - p0));
+        apdf = em.area_pdf;
+    }
+    F3 dir = p - ref;
+    float dist = norm(dir);
+    wi = normalized(dir); ln = n; lp = p;
+    shadow.o = p; shadow.d = -wi; shadow.mint = 1e-3f; shadow.maxt = dist - 1e-3f;
+    float pdfv = emitter_pdf(shape_area_pdf(sc, shp), ref, p, n, wi);
+    (void) apdf;
+    if (fabsf(pdfv) > 1e-6) return f3(em.radiance) / pdfv;
+    return f3(0.f);
+}
+
+// ---- one path, PathMisIntegrator::Li (src/pathMisIntegrator.cpp:18-168) ---------------------------------
+// State kept between bounces (what the reference keeps in locals across iterations of its while(true)).
+struct PathState {
+    Ray ray; F3 t, li; float last_bsdf_pdf; bool last_delta;
+};
+__device__ __forceinline__ void path_init(PathState &ps, const Ray &r) {
+    ps.ray = r; ps.t = f3(1.0f); ps.li = f3(0.f); ps.last_bsdf_pdf = 1.0f; ps.last_delta = true;
+}
+struct Counters { uint32_t closest, shadow, nodes, prims; };
+
+// One iteration of the reference's bounce loop.  Returns false when the path has ended.
+// A zero BSDF weight ends the path: the reference keeps bouncing with zero throughput, which adds exact zeros.
+template <typename StackT>
+__device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
+    Hit hit;
+    ctr.closest++;
+    if (!trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+    Surface sf;
+    surface_from_hit(sc, ps.ray, hit, sf, false);
+    const NoriHipShape &shp = sc.shapes[sf.shape];
+    if (shp.emitter >= 0) {                                               // :42-63
+        const NoriHipEmitter &em = sc.emitters[shp.emitter];
+        F3 wi = normalized(sf.p - ps.ray.o);
+        F3 flight = (dot(sf.sh.n, wi) < 0) ? f3(em.radiance) : f3(0.f);
+        float light_pdf = emitter_pdf(shape_area_pdf(sc, shp), ps.ray.o, sf.p, sf.sh.n, wi);
+        float wmat = ps.last_bsdf_pdf / (light_pdf + ps.last_bsdf_pdf);
+        if (ps.last_delta) wmat = 1.0f;
+        if (wmat > 0.0f) ps.li = ps.li + (wmat * ps.t) * flight;
+    }
+    const float successProb = 0.95f;                                      // :67-77
+    if (rng.next1D() > successProb) return false;
+    ps.t = ps.t / successProb;
+
+    F3 wi_l = sf.sh.toLocal(-ps.ray.d);                                   // :81-109
+    F2 s2 = rng.next2D(); F2 s1 = rng.next2D(); (void) s2;                // second argument is drawn first
+    F3 wo; bool is_delta, wo_valid;
+    F3 f = bsdf_sample(shp, wi_l, s1, wo, is_delta, wo_valid);
+    ps.last_bsdf_pdf = wo_valid ? bsdf_pdf(shp, wi_l, wo) : 0.0f;
+    ps.last_delta = is_delta;
+    F3 next_dir = wo_valid ? normalized(sf.sh.toWorld(wo)) : f3(0.f);
+
+    float pick = rng.next1D();                                            // :114 (drawn for delta BSDFs too)
+    if (!is_delta) {
+        uint32_t n = sc.n_emitters;
+        uint32_t index = (uint32_t) floorf((float) n * pick); if (index > n - 1) index = n - 1;
+        const NoriHipEmitter &em = sc.emitters[index];
+        F3 lwi, ln, lp; Ray shadow;
+        F3 liLoc = emitter_sample(sc, em, sf.p, rng.next2D(), lwi, ln, lp, shadow);
+        Hit sh_hit;
+        ctr.shadow++;
+        if (!trace<true>(sc, shadow, sh_hit, stk, ctr.nodes, ctr.prims)) {
+            F3 wo_l = sf.sh.toLocal(lwi);
+            float bpdf = bsdf_pdf(shp, wi_l, wo_l);
+            float lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), sf.p, lp, ln, lwi);
+            float wem = lpdf / (lpdf + bpdf);
+            float cosS = dot(normalized(lwi), normalized(sf.sh.n));
+            if (wem > 0) ps.li = ps.li + ((((ps.t * wem) * liLoc) * bsdf_eval(shp, wi_l, wo_l)) * fabsf(cosS)) * (float) n;
+        }
+    }
+    if (!wo_valid || is_zero(f)) return false;
+    ps.ray.d = next_dir; ps.ray.o = sf.p; ps.ray.mint = 1e-3f; ps.ray.maxt = ND_INF;
+    ps.t = ps.t * f;
+    return true;
+}
+
+} // namespace nd

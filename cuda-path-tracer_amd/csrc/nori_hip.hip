@@ -1,0 +1,529 @@
+// libnori_hip.so — gfx950 kernels and the C ABI of include/nori_hip.h.
+//
+// Kernels
+//   k_trace        one ray per lane, closest- or any-hit (BVH::rayIntersect, src/bvh.cpp:404-463)
+//   k_camera_rays  PerspectiveCamera::sampleRay (src/perspective.cpp:90-111)
+//   k_li_samples   one camera sample per lane, seeded per sample (parity entry)
+//   k_render       persistent lanes with per-lane path regeneration: every lane runs one bounce of
+//                  PathMisIntegrator::Li per loop trip (extend -> shade -> shadow), and a lane whose path ended
+//                  splats it to the film and draws the next camera sample from a global counter, so waves stay
+//                  full until the work runs out (src/render.cpp:72-101 + src/pathMisIntegrator.cpp:18-168)
+//   k_bitmap       ImageBlock::toBitmap (src/block.cpp:76-82)
+//   k_srgb, k_nlmeans   the filter pass of the CUDA fork (cuda/filter.cc.cu:33-110)
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include "nori_device.h"
+
+#pragma clang fp contract(off)
+
+using namespace nd;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &m) { g_err = m; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(NORI_HIP_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims; };
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *rays, size_t n, int any_hit, NoriHipHit *hits, float *full) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+    float4 a = rp[0], b = rp[1];
+    Ray ray; ray.o = f3(a.x, a.y, a.z); ray.mint = a.w; ray.d = f3(b.x, b.y, b.z); ray.maxt = b.w;
+    ScratchStack stk; Hit hit; uint32_t nn = 0, np = 0;
+    NoriHipHit out; out.prim = NORI_HIP_MISS; out.t = 0.f; out.u = 0.f; out.v = 0.f;
+    if (any_hit) {
+        if (trace<true>(sc, ray, hit, stk, nn, np)) out.prim = 1u;
+        hits[i] = out;
+        return;
+    }
+    bool found = trace<false>(sc, ray, hit, stk, nn, np);
+    if (found) {
+        Surface sf; surface_from_hit(sc, ray, hit, sf, true);
+        out.prim = sf.prim; out.t = hit.t; out.u = sf.uv.x; out.v = sf.uv.y;
+        if (full) {
+            float *f = full + 16 * i;
+            f[0] = sf.p.x; f[1] = sf.p.y; f[2] = sf.p.z; f[3] = sf.uv.x; f[4] = sf.uv.y;
+            f[5] = sf.sh.n.x; f[6] = sf.sh.n.y; f[7] = sf.sh.n.z; f[8] = sf.geo_n.x; f[9] = sf.geo_n.y; f[10] = sf.geo_n.z;
+            f[11] = (float) sf.shape; f[12] = f[13] = f[14] = f[15] = 0.f;
+        }
+    } else if (full) { float *f = full + 16 * i; for (int k = 0; k < 16; ++k) f[k] = 0.f; }
+    hits[i] = out;
+}
+
+__global__ __launch_bounds__(256) void k_camera_rays(DevScene sc, const float *ps, size_t n, NoriHipRay *rays) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r; camera_ray(sc, f2(ps[2 * i], ps[2 * i + 1]), r);
+    NoriHipRay o; o.o[0] = r.o.x; o.o[1] = r.o.y; o.o[2] = r.o.z; o.mint = r.mint; o.d[0] = r.d.x; o.d[1] = r.d.y; o.d[2] = r.d.z; o.maxt = r.maxt;
+    rays[i] = o;
+}
+
+__global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const int32_t *px, const int32_t *py, const uint64_t *states,
+                                                    const uint64_t *seqs, const NoriHipRay *rays, float *rgb) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Pcg32 rng; rng.seed(states[i], seqs[i]);
+    F2 j = rng.next2D(); (void) rng.next2D();
+    Ray ray;
+    if (rays) { const NoriHipRay &q = rays[i]; ray.o = f3(q.o); ray.d = f3(q.d); ray.mint = q.mint; ray.maxt = q.maxt; }
+    else if (px) camera_ray(sc, f2((float) px[i] + j.x, (float) py[i] + j.y), ray);
+    else camera_ray(sc, f2(j.x * (float) sc.cam.width, j.y * (float) sc.cam.height), ray);      // src/ttest.cpp:171-172
+    PathState ps; path_init(ps, ray);
+    ScratchStack stk; Counters c = {0, 0, 0, 0};
+    while (path_bounce(sc, ps, rng, stk, c)) { }
+    rgb[3 * i] = ps.li.x; rgb[3 * i + 1] = ps.li.y; rgb[3 * i + 2] = ps.li.z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct RenderJob {
+    int x0, y0, tw, th;               // tile origin and size
+    int spp_begin, nspp;
+    unsigned long long total;         // tw*th*nspp work items
+};
+
+// Work item w -> (8x8 pixel patch, sample, lane): the 64 items of a chunk are the 64 pixels of one patch for one
+// sample index, so the primary rays of a freshly started wave are coherent.
+__device__ __forceinline__ void work_to_sample(const RenderJob &job, unsigned long long w, int &px, int &py, int &s) {
+    unsigned int lane = (unsigned int) (w & 63u);
+    unsigned long long chunk = w >> 6;
+    int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
+    unsigned long long patch = chunk / (unsigned long long) job.nspp;
+    s = job.spp_begin + (int) (chunk % (unsigned long long) job.nspp);
+    int pyi = (int) (patch / (unsigned long long) ptx), pxi = (int) (patch % (unsigned long long) ptx);
+    (void) pty;
+    px = job.x0 + pxi * 8 + (int) (lane & 7u);
+    py = job.y0 + pyi * 8 + (int) (lane >> 3);
+}
+
+// ImageBlock::put(sample) as written (src/block.cpp:93-111: single-pixel add, then return) in the coordinates of
+// the sample's 32x32 block, moved into the full film as ImageBlock::put(ImageBlock&) does (:131-140).
+__device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 pos, int px, int py, F3 v) {
+    if (!color_valid(v)) return false;
+    int ox = (px >> 5) << 5, oy = (py >> 5) << 5;
+    float fx = pos.x - 0.5f - (float) (ox - sc.border), fy = pos.y - 0.5f - (float) (oy - sc.border);
+    int ix = (int) fx + ox, iy = (int) fy + oy;
+    float *p = reinterpret_cast<float *>(film + (size_t) iy * sc.film_cols + ix);
+    unsafeAtomicAdd(p + 0, v.x); unsafeAtomicAdd(p + 1, v.y); unsafeAtomicAdd(p + 2, v.z); unsafeAtomicAdd(p + 3, 1.0f);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_render(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats) {
+    ScratchStack stk;
+    Counters ctr = {0, 0, 0, 0};
+    unsigned int n_samples = 0, n_invalid = 0;
+    PathState ps; Pcg32 rng; F2 pixel_sample = f2(0.f, 0.f); int px = 0, py = 0;
+    bool alive = false, exhausted = false;
+    const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
+    const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
+    for (;;) {
+        if (!alive && !exhausted) {
+            // draw the next work item (hipcc merges the per-lane atomics of a wave into one)
+            for (;;) {
+                unsigned long long w = atomicAdd(work_counter, 1ull);
+                if (w >= padded_total) { exhausted = true; break; }
+                int s; work_to_sample(job, w, px, py, s);
+                if (px >= job.x0 + job.tw || py >= job.y0 + job.th) continue;          // padding of edge patches
+                rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) s);
+                F2 j = rng.next2D();
+                pixel_sample = f2((float) px + j.x, (float) py + j.y);
+                (void) rng.next2D();                                                  // aperture sample, src/render.cpp:86
+                Ray r; camera_ray(sc, pixel_sample, r);
+                path_init(ps, r);
+                alive = true; n_samples++;
+                break;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;                                           // whole wave out of work
+        if (alive) {
+            if (!path_bounce(sc, ps, rng, stk, ctr)) {
+                if (!film_put(sc, film, pixel_sample, px, py, ps.li)) n_invalid++;
+                alive = false;
+            }
+        }
+    }
+    // per-wave reduction of the counters, one atomic per wave
+    unsigned long long v[6] = {n_samples, ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
+    for (int k = 0; k < 6; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        v[k] = x;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats->samples, v[0]); atomicAdd(&stats->closest, v[1]); atomicAdd(&stats->shadow, v[2]);
+        atomicAdd(&stats->invalid, v[3]); atomicAdd(&stats->nodes, v[4]); atomicAdd(&stats->prims, v[5]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_bitmap(const float4 *film, int w, int h, int border, int cols, float *rgb) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float4 c = film[(size_t) (y + border) * cols + (x + border)];
+    float *o = rgb + ((size_t) y * w + x) * 3;
+    if (c.w != 0) { o[0] = c.x / c.w; o[1] = c.y / c.w; o[2] = c.z / c.w; } else { o[0] = o[1] = o[2] = 0.f; }
+}
+
+// Color3f::toSRGB (src/common.cpp:192-206)
+__device__ __forceinline__ float to_srgb(float v) { return v <= 0.0031308f ? 12.92f * v : (1.0f + 0.055f) * powf(v, 1.0f / 2.4f) - 0.055f; }
+__global__ void k_srgb(const float *rgb, size_t n, float *out) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = to_srgb(rgb[i]);
+}
+
+// NL-means (cuda/filter.cc.cu:53-110 + the normalisation of copy_weighted_data_to_surface :33-48).
+// One output pixel per lane; the (2r+2f+1)^2 neighbourhood of a 16x16 pixel block is staged in LDS.
+#define NLM_BW 16
+#define NLM_BH 16
+__global__ __launch_bounds__(NLM_BW * NLM_BH) void k_nlmeans(const float *img, float *out, int w, int h, int r, int f, float sigma, float hh) {
+    extern __shared__ float lds[];          // (NLM_BH + 2R) x (NLM_BW + 2R) x 3, R = r + f
+    const int R = r + f;
+    const int tw = NLM_BW + 2 * R, th = NLM_BH + 2 * R;
+    const int bx = blockIdx.x * NLM_BW, by = blockIdx.y * NLM_BH;
+    for (int i = threadIdx.y * NLM_BW + threadIdx.x; i < tw * th; i += NLM_BW * NLM_BH) {
+        int ly = i / tw, lx = i % tw;
+        int gx = bx + lx - R, gy = by + ly - R;
+        float a = 0.f, b = 0.f, c = 0.f;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) { const float *p = img + ((size_t) gy * w + gx) * 3; a = p[0]; b = p[1]; c = p[2]; }
+        lds[3 * i] = a; lds[3 * i + 1] = b; lds[3 * i + 2] = c;
+    }
+    __syncthreads();
+    const int x = bx + threadIdx.x, y = by + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const float sigma2 = sigma * sigma, h2 = hh * hh;
+    const int minX = max(0, x - r), maxX = min(w - 1, x + r), minY = max(0, y - r), maxY = min(h - 1, y + r);
+    float wsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = minX; i <= maxX; ++i) for (int j = minY; j <= maxY; ++j) {
+        float d2 = 0.f;
+        int pminx = max(max(-f, -x), -i), pmaxx = min(min(f, w - x - 1), w - i - 1);
+        int pminy = max(max(-f, -y), -j), pmaxy = min(min(f, h - y - 1), h - j - 1);
+        for (int k = pminx; k <= pmaxx; ++k) for (int l = pminy; l <= pmaxy; ++l) {
+            const float *p = &lds[3 * ((y + l - by + R) * tw + (x + k - bx + R))];
+            const float *q = &lds[3 * ((j + l - by + R) * tw + (i + k - bx + R))];
+            float wk = expf(-(float) (k * k + l * l) / (2.0f * sigma2));
+            float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+            float patchv = (dx * dx + dy * dy + dz * dz) / h2;
+            d2 += wk * patchv;
+        }
+        d2 /= (float) ((pmaxx - pminx + 1) * (pmaxy - pminy + 1));
+        float wgt = expf(-fmaxf(d2, 0.0f));
+        wsum += wgt;
+        const float *c = &lds[3 * ((j - by + R) * tw + (i - bx + R))];
+        a0 += wgt * c[0]; a1 += wgt * c[1]; a2 += wgt * c[2];
+    }
+    float *o = out + ((size_t) y * w + x) * 3;
+    o[0] = a0 / wsum; o[1] = a1 / wsum; o[2] = a2 / wsum;
+}
+
+template <typename T> int upload(T *&dptr, const T *src, size_t n) {
+    dptr = nullptr;
+    if (n == 0) return NORI_HIP_OK;
+    HIPCHK(hipMalloc((void **) &dptr, n * sizeof(T)));
+    HIPCHK(hipMemcpy(dptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return NORI_HIP_OK;
+}
+
+} // namespace
+
+struct NoriHipContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool have_scene = false;
+    DevScene sc;
+    NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
+    NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
+    float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
+    unsigned long long *d_counter = nullptr; DevStats *d_stats = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    NoriHipStats stats;
+    int n_cus = 256;
+    void free_scene() {
+        hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
+        d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
+        have_scene = false;
+    }
+};
+
+#define CTXCHK(ctx) do { if (!(ctx)) return fail(NORI_HIP_EINVAL, "null context"); HIPCHK(hipSetDevice((ctx)->device)); } while (0)
+#define SCENECHK(ctx) do { CTXCHK(ctx); if (!(ctx)->have_scene) return fail(NORI_HIP_ESTATE, "no scene uploaded"); } while (0)
+
+extern "C" {
+
+const char *nori_hip_last_error(void) { return g_err.c_str(); }
+
+int nori_hip_create(int device, NoriHipContext **out) {
+    if (!out) return fail(NORI_HIP_EINVAL, "out is null");
+    int count = 0;
+    HIPCHK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(NORI_HIP_EDEVICE, "no such HIP device " + std::to_string(device));
+    HIPCHK(hipSetDevice(device));
+    NoriHipContext *c = new NoriHipContext();
+    c->device = device;
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->n_cus = prop.multiProcessorCount;
+    HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipMalloc((void **) &c->d_counter, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **) &c->d_stats, sizeof(DevStats)));
+    HIPCHK(hipMemset(c->d_stats, 0, sizeof(DevStats)));
+    std::memset(&c->stats, 0, sizeof(c->stats));
+    *out = c;
+    return NORI_HIP_OK;
+}
+
+int nori_hip_destroy(NoriHipContext *ctx) {
+    if (!ctx) return NORI_HIP_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    ctx->free_scene();
+    hipFree(ctx->d_counter); hipFree(ctx->d_stats);
+    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return NORI_HIP_OK;
+}
+
+int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
+    CTXCHK(ctx);
+    if (!d) return fail(NORI_HIP_EINVAL, "scene description is null");
+    if (d->n_prims == 0 || !d->prims || !d->shade_prims) return fail(NORI_HIP_EINVAL, "scene has no primitives");
+    if (d->n_shapes == 0 || !d->shapes) return fail(NORI_HIP_EINVAL, "scene has no shapes");
+    if (d->n_nodes > 0 && !d->nodes) return fail(NORI_HIP_EINVAL, "nodes is null");
+    if (d->camera.width <= 0 || d->camera.height <= 0) return fail(NORI_HIP_EINVAL, "bad camera size");
+    // validate every index the kernels will follow: a bad table must be rejected here, not fault on the GPU
+    auto ref_ok = [&](uint32_t r) {
+        if (r == NORI_HIP_NO_CHILD) return true;
+        if (r & NORI_HIP_LEAF_BIT) return (r & 0x7fffffffu) < d->n_prims;
+        return r < d->n_nodes;
+    };
+    if (d->root == NORI_HIP_NO_CHILD || !ref_ok(d->root)) return fail(NORI_HIP_EINVAL, "bad root reference");
+    for (uint32_t i = 0; i < d->n_nodes; ++i)
+        if (!ref_ok(d->nodes[i].left) || d->nodes[i].left == NORI_HIP_NO_CHILD || !ref_ok(d->nodes[i].right))
+            return fail(NORI_HIP_EINVAL, "node " + std::to_string(i) + " has a child reference out of range");
+    if (!(d->prims[d->n_prims - 1].shape_flags & 0x80000000u)) return fail(NORI_HIP_EINVAL, "last primitive record does not end a leaf");
+    for (uint32_t i = 0; i < d->n_prims; ++i)
+        if ((d->prims[i].shape_flags & 0xffffffu) >= d->n_shapes) return fail(NORI_HIP_EINVAL, "primitive record " + std::to_string(i) + " names a shape out of range");
+    for (uint32_t i = 0; i < d->n_shapes; ++i) {
+        const NoriHipShape &s = d->shapes[i];
+        if (s.emitter >= (int32_t) d->n_emitters) return fail(NORI_HIP_EINVAL, "shape emitter index out of range");
+        if (s.bsdf < 0 || s.bsdf > NORI_HIP_BSDF_MIRROR) return fail(NORI_HIP_EINVAL, "unknown BSDF kind");
+    }
+    for (uint32_t i = 0; i < d->n_emitters; ++i) {
+        const NoriHipEmitter &e = d->emitters[i];
+        if (e.shape < 0 || e.shape >= (int32_t) d->n_shapes) return fail(NORI_HIP_EINVAL, "emitter shape index out of range");
+        if (d->shapes[e.shape].type == NORI_HIP_SHAPE_MESH) {
+            if (e.n_tris == 0 || (uint64_t) e.cdf_offset + e.n_tris + 1 > d->n_cdf) return fail(NORI_HIP_EINVAL, "emitter cdf range out of bounds");
+            if ((uint64_t) e.light_prim_offset + e.n_tris > d->n_light_prims) return fail(NORI_HIP_EINVAL, "emitter light_prims range out of bounds");
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->free_scene();
+    int rc;
+    if ((rc = upload(ctx->d_nodes, d->nodes, d->n_nodes))) return rc;
+    if ((rc = upload(ctx->d_prims, d->prims, d->n_prims))) return rc;
+    if ((rc = upload(ctx->d_shade, d->shade_prims, d->n_prims))) return rc;
+    if ((rc = upload(ctx->d_light, d->light_prims, d->n_light_prims))) return rc;
+    if ((rc = upload(ctx->d_shapes, d->shapes, d->n_shapes))) return rc;
+    if ((rc = upload(ctx->d_emitters, d->emitters, d->n_emitters))) return rc;
+    if ((rc = upload(ctx->d_cdf, d->cdf, d->n_cdf))) return rc;
+    DevScene &sc = ctx->sc;
+    sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
+    sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
+    sc.root = d->root; sc.n_emitters = d->n_emitters;
+    for (int i = 0; i < 3; ++i) { sc.root_min[i] = d->root_min[i]; sc.root_max[i] = d->root_max[i]; }
+    sc.cam = d->camera;
+    sc.inv_w = 1.0f / (float) d->camera.width; sc.inv_h = 1.0f / (float) d->camera.height;
+    ctx->border = (int) std::ceil(d->camera.filter_radius - 0.5f);
+    if (ctx->border < 0) ctx->border = 0;
+    ctx->film_rows = d->camera.height + 2 * ctx->border; ctx->film_cols = d->camera.width + 2 * ctx->border;
+    sc.border = ctx->border; sc.film_cols = ctx->film_cols;
+    HIPCHK(hipMalloc((void **) &ctx->d_film, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4)));
+    HIPCHK(hipMemset(ctx->d_film, 0, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4)));
+    ctx->have_scene = true;
+    return NORI_HIP_OK;
+}
+
+int nori_hip_trace_device(NoriHipContext *ctx, const NoriHipRay *d_rays, size_t n, int any_hit, NoriHipHit *d_hits) {
+    SCENECHK(ctx);
+    if (n == 0) return NORI_HIP_OK;
+    if (!d_rays || !d_hits) return fail(NORI_HIP_EINVAL, "null ray/hit buffer");
+    unsigned blocks = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(k_trace, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sc, d_rays, n, any_hit, d_hits, (float *) nullptr);
+    HIPCHK(hipGetLastError());
+    return NORI_HIP_OK;
+}
+
+int nori_hip_trace(NoriHipContext *ctx, const NoriHipRay *rays, size_t n, int any_hit, NoriHipHit *hits, float *full) {
+    SCENECHK(ctx);
+    if (n == 0) return NORI_HIP_OK;
+    if (!rays || !hits) return fail(NORI_HIP_EINVAL, "null ray/hit buffer");
+    NoriHipRay *d_rays = nullptr; NoriHipHit *d_hits = nullptr; float *d_full = nullptr;
+    HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay)));
+    HIPCHK(hipMalloc((void **) &d_hits, n * sizeof(NoriHipHit)));
+    if (full) HIPCHK(hipMalloc((void **) &d_full, n * 16 * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream));
+    unsigned blocks = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(k_trace, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sc, (const NoriHipRay *) d_rays, n, any_hit, d_hits, d_full);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hits, d_hits, n * sizeof(NoriHipHit), hipMemcpyDeviceToHost, ctx->stream));
+    if (full) HIPCHK(hipMemcpyAsync(full, d_full, n * 16 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d_rays); hipFree(d_hits); hipFree(d_full);
+    return NORI_HIP_OK;
+}
+
+int nori_hip_camera_rays(NoriHipContext *ctx, const float *ps, size_t n, NoriHipRay *rays) {
+    SCENECHK(ctx);
+    if (n == 0) return NORI_HIP_OK;
+    if (!ps || !rays) return fail(NORI_HIP_EINVAL, "null buffer");
+    float *d_ps = nullptr; NoriHipRay *d_rays = nullptr;
+    HIPCHK(hipMalloc((void **) &d_ps, n * 2 * sizeof(float)));
+    HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay)));
+    HIPCHK(hipMemcpyAsync(d_ps, ps, n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_camera_rays, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, (const float *) d_ps, n, d_rays);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rays, d_rays, n * sizeof(NoriHipRay), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d_ps); hipFree(d_rays);
+    return NORI_HIP_OK;
+}
+
+int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const int32_t *py, const uint64_t *states, const uint64_t *seqs,
+                        const NoriHipRay *rays, float *rgb) {
+    SCENECHK(ctx);
+    if (n == 0) return NORI_HIP_OK;
+    if (!states || !seqs || !rgb || ((px == nullptr) != (py == nullptr))) return fail(NORI_HIP_EINVAL, "null buffer");
+    if (ctx->sc.n_emitters == 0) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
+    int32_t *d_px = nullptr, *d_py = nullptr; uint64_t *d_st = nullptr, *d_sq = nullptr; NoriHipRay *d_rays = nullptr; float *d_rgb = nullptr;
+    if (px) { HIPCHK(hipMalloc((void **) &d_px, n * 4)); HIPCHK(hipMemcpyAsync(d_px, px, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
+    if (py) { HIPCHK(hipMalloc((void **) &d_py, n * 4)); HIPCHK(hipMemcpyAsync(d_py, py, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
+    HIPCHK(hipMalloc((void **) &d_st, n * 8)); HIPCHK(hipMemcpyAsync(d_st, states, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMalloc((void **) &d_sq, n * 8)); HIPCHK(hipMemcpyAsync(d_sq, seqs, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (rays) { HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay))); HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream)); }
+    HIPCHK(hipMalloc((void **) &d_rgb, n * 12));
+    hipLaunchKernelGGL(k_li_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
+                       (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d_px); hipFree(d_py); hipFree(d_st); hipFree(d_sq); hipFree(d_rays); hipFree(d_rgb);
+    return NORI_HIP_OK;
+}
+
+int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp_begin, int spp_end) {
+    SCENECHK(ctx);
+    const int W = ctx->sc.cam.width, H = ctx->sc.cam.height;
+    if (x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 >= x1 || y0 >= y1) return fail(NORI_HIP_EINVAL, "tile outside the image");
+    if (spp_begin < 0 || spp_end <= spp_begin) return fail(NORI_HIP_EINVAL, "empty sample range");
+    if (ctx->sc.n_emitters == 0) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
+    RenderJob job; job.x0 = x0; job.y0 = y0; job.tw = x1 - x0; job.th = y1 - y0; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin;
+    job.total = (unsigned long long) job.tw * job.th * job.nspp;
+    HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
+    // persistent grid: enough resident waves to cover latency, capped by the amount of work
+    unsigned long long chunks = (job.total + 255) / 256;
+    unsigned blocks = (unsigned) ctx->n_cus * 8u;
+    if ((unsigned long long) blocks > chunks) blocks = (unsigned) chunks;
+    if (blocks == 0) blocks = 1;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_render, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->stats.iterations = 1;
+    return NORI_HIP_OK;
+}
+
+int nori_hip_clear_film(NoriHipContext *ctx) {
+    SCENECHK(ctx);
+    HIPCHK(hipMemsetAsync(ctx->d_film, 0, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4), ctx->stream));
+    return NORI_HIP_OK;
+}
+int nori_hip_film_dims(NoriHipContext *ctx, int *rows, int *cols, int *border) {
+    SCENECHK(ctx);
+    if (rows) *rows = ctx->film_rows; if (cols) *cols = ctx->film_cols; if (border) *border = ctx->border;
+    return NORI_HIP_OK;
+}
+int nori_hip_read_film(NoriHipContext *ctx, float *film) {
+    SCENECHK(ctx);
+    if (!film) return fail(NORI_HIP_EINVAL, "null buffer");
+    HIPCHK(hipMemcpyAsync(film, ctx->d_film, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NORI_HIP_OK;
+}
+int nori_hip_write_film(NoriHipContext *ctx, const float *film) {
+    SCENECHK(ctx);
+    if (!film) return fail(NORI_HIP_EINVAL, "null buffer");
+    HIPCHK(hipMemcpyAsync(ctx->d_film, film, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NORI_HIP_OK;
+}
+int nori_hip_film_device_ptr(NoriHipContext *ctx, void **d_film, size_t *bytes) {
+    SCENECHK(ctx);
+    if (d_film) *d_film = ctx->d_film;
+    if (bytes) *bytes = (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4);
+    return NORI_HIP_OK;
+}
+int nori_hip_read_bitmap(NoriHipContext *ctx, float *rgb) {
+    SCENECHK(ctx);
+    if (!rgb) return fail(NORI_HIP_EINVAL, "null buffer");
+    const int W = ctx->sc.cam.width, H = ctx->sc.cam.height;
+    float *d = nullptr; HIPCHK(hipMalloc((void **) &d, (size_t) W * H * 12));
+    hipLaunchKernelGGL(k_bitmap, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rgb, d, (size_t) W * H * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d);
+    return NORI_HIP_OK;
+}
+
+int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, float *out) {
+    SCENECHK(ctx);
+    if (!out) return fail(NORI_HIP_EINVAL, "null buffer");
+    if (r < 0 || f < 0 || !(sigma > 0) || !(h > 0)) return fail(NORI_HIP_EINVAL, "bad filter parameters");
+    const int W = ctx->sc.cam.width, H = ctx->sc.cam.height, R = r + f;
+    size_t lds = (size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 * sizeof(float);
+    if (lds > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile (r + f <= 48)");
+    size_t n = (size_t) W * H * 3;
+    float *d_lin = nullptr, *d_srgb = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void **) &d_lin, n * 4)); HIPCHK(hipMalloc((void **) &d_srgb, n * 4)); HIPCHK(hipMalloc((void **) &d_out, n * 4));
+    hipLaunchKernelGGL(k_bitmap, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d_lin);
+    hipLaunchKernelGGL(k_srgb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float *) d_lin, n, d_srgb);
+    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_nlmeans, dim3((W + NLM_BW - 1) / NLM_BW, (H + NLM_BH - 1) / NLM_BH), dim3(NLM_BW, NLM_BH), lds, ctx->stream,
+                       (const float *) d_srgb, d_out, W, H, r, f, sigma, h);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(d_lin); hipFree(d_srgb); hipFree(d_out);
+    return NORI_HIP_OK;
+}
+
+int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
+    CTXCHK(ctx);
+    if (!out) return fail(NORI_HIP_EINVAL, "null buffer");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    DevStats ds; HIPCHK(hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
+    ctx->stats.camera_samples = ds.samples; ctx->stats.closest_rays = ds.closest; ctx->stats.shadow_rays = ds.shadow; ctx->stats.invalid_samples = ds.invalid;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->stats.render_ms = ms; else (void) hipGetLastError();
+    ctx->stats.boxes_tested = ds.nodes; ctx->stats.prims_tested = ds.prims;
+    *out = ctx->stats;
+    return NORI_HIP_OK;
+}
+int nori_hip_reset_stats(NoriHipContext *ctx) {
+    CTXCHK(ctx);
+    HIPCHK(hipMemsetAsync(ctx->d_stats, 0, sizeof(DevStats), ctx->stream));
+    return NORI_HIP_OK;
+}
+int nori_hip_stream(NoriHipContext *ctx, void **stream) { CTXCHK(ctx); if (stream) *stream = ctx->stream; return NORI_HIP_OK; }
+int nori_hip_synchronize(NoriHipContext *ctx) { CTXCHK(ctx); HIPCHK(hipStreamSynchronize(ctx->stream)); return NORI_HIP_OK; }
+
+} // extern "C"

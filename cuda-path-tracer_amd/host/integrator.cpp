@@ -1,0 +1,181 @@
+// The path_mis integrator plugin backed by libnori_hip.so, the t-test plugin, and the headless render driver.
+// Reference: src/pathMisIntegrator.cpp:175 (NORI_REGISTER_CLASS(PathMisIntegrator, "path_mis")),
+//            include/nori/integrator.h:35-62, src/render.cpp:103-214, src/ttest.cpp:58-220,
+//            ext/hypothesis/hypothesis.h:313-346 (students_t_test).
+#include "scene.h"
+#include "render.h"
+#include <cstring>
+#include <iostream>
+#include <fstream>
+
+namespace nori {
+
+static void hipCheck(int rc, const char *what) {
+    if (rc != NORI_HIP_OK) throw NoriException::format("%s failed: %s", what, nori_hip_last_error());
+}
+
+/// GPU path tracer with multiple importance sampling.  Registered as "path_mis" (so existing scene files select
+/// it unchanged) and as "path_mis_hip".  Properties: device (int, default 0 or $NORI_HIP_DEVICE).
+class PathMisHip : public GpuIntegrator {
+public:
+    explicit PathMisHip(const PropertyList &props) {
+        const char *env = getenv("NORI_HIP_DEVICE");
+        m_device = props.getInteger("device", env ? atoi(env) : 0);
+    }
+    ~PathMisHip() override { if (m_ctx) nori_hip_destroy(m_ctx); }
+    void preprocess(const Scene *scene) override {
+        flattenScene(scene, m_flat);
+        if (m_flat.desc.n_emitters == 0) throw NoriException("path_mis: the scene has no emitters");
+        if (!m_ctx) hipCheck(nori_hip_create(m_device, &m_ctx), "nori_hip_create");
+        hipCheck(nori_hip_upload_scene(m_ctx, &m_flat.desc), "nori_hip_upload_scene");
+    }
+    void render(const Scene *scene, int spp_begin, int spp_end) override {
+        if (!m_ctx) preprocess(scene);
+        const NoriHipCamera &c = m_flat.desc.camera;
+        hipCheck(nori_hip_render(m_ctx, 0, 0, c.width, c.height, spp_begin, spp_end), "nori_hip_render");
+    }
+    void readFilm(std::vector<float> &film, int &rows, int &cols, int &border) override {
+        need(); hipCheck(nori_hip_film_dims(m_ctx, &rows, &cols, &border), "nori_hip_film_dims");
+        film.resize((size_t) rows * cols * 4); hipCheck(nori_hip_read_film(m_ctx, film.data()), "nori_hip_read_film");
+    }
+    void readBitmap(std::vector<float> &rgb) override {
+        need(); const NoriHipCamera &c = m_flat.desc.camera;
+        rgb.resize((size_t) c.width * c.height * 3); hipCheck(nori_hip_read_bitmap(m_ctx, rgb.data()), "nori_hip_read_bitmap");
+    }
+    NoriHipContext *context() override { return m_ctx; }
+    const FlatScene &flat() const override { return m_flat; }
+    std::string toString() const override { return "PathMisIntegrator[backend=hip/gfx950]"; }
+private:
+    void need() const { if (!m_ctx) throw NoriException("path_mis: preprocess() has not run"); }
+    int m_device = 0; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
+};
+static NoriObject *PathMisHip_create(const PropertyList &l) { return new PathMisHip(l); }
+static struct PathMisHip_reg { PathMisHip_reg() { NoriObjectFactory::registerClass("path_mis", PathMisHip_create); NoriObjectFactory::registerClass("path_mis_hip", PathMisHip_create); } } PathMisHip_reg_;
+
+/// The reference's test files also name integrators that are outside this build's scope.  They are
+/// accepted by the parser so those files load unmodified, and refuse to render.
+class OutOfScopeIntegrator : public Integrator {
+public:
+    OutOfScopeIntegrator(const PropertyList &, const char *name) : m_name(name) {}
+    void render(const Scene *, int, int) override { fail(); }
+    void readFilm(std::vector<float> &, int &, int &, int &) override { fail(); }
+    void readBitmap(std::vector<float> &) override { fail(); }
+    std::string toString() const override { return m_name + "[out of scope in this build]"; }
+private:
+    [[noreturn]] void fail() const { throw NoriException::format("integrator \"%s\" is outside the path_mis hot path and is not implemented by this build", m_name.c_str()); }
+    std::string m_name;
+};
+static struct OutOfScope_reg { OutOfScope_reg() {
+    for (const char *n : {"path_mats", "direct_mis", "direct_ems", "direct_mats", "direct", "av", "normals", "photonmapper"})
+        NoriObjectFactory::registerClass(n, [n](const PropertyList &l) -> NoriObject * { return new OutOfScopeIntegrator(l, n); });
+} } OutOfScope_reg_;
+
+// ---- Student's t-test -------------------------------------------------------------------------------------
+// regularised incomplete beta by Lentz's continued fraction; enough for the CDF of Student's t
+static double betacf(double a, double b, double x) {
+    const double tiny = 1e-300; double qab = a + b, qap = a + 1, qam = a - 1, c = 1, d = 1 - qab * x / qap;
+    if (std::fabs(d) < tiny) d = tiny; d = 1 / d; double h = d;
+    for (int m = 1; m <= 500; ++m) {
+        int m2 = 2 * m; double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1 + aa * d; if (std::fabs(d) < tiny) d = tiny; c = 1 + aa / c; if (std::fabs(c) < tiny) c = tiny; d = 1 / d; h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1 + aa * d; if (std::fabs(d) < tiny) d = tiny; c = 1 + aa / c; if (std::fabs(c) < tiny) c = tiny; d = 1 / d;
+        double del = d * c; h *= del; if (std::fabs(del - 1) < 1e-15) break;
+    }
+    return h;
+}
+static double incbeta(double a, double b, double x) {
+    if (x <= 0) return 0; if (x >= 1) return 1;
+    double bt = std::exp(std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log(1 - x));
+    if (x < (a + 1) / (a + b + 2)) return bt * betacf(a, b, x) / a;
+    return 1 - bt * betacf(b, a, 1 - x) / b;
+}
+double studentsTCdf(double t, double dof) { double x = dof / (dof + t * t); double tail = 0.5 * incbeta(dof / 2, 0.5, x); return t >= 0 ? 1 - tail : tail; }
+
+TTestResult studentsTTest(double mean, double variance, double reference, int sampleCount, double significanceLevel, int numTests) {
+    TTestResult r; r.mean = mean; r.variance = variance; r.reference = reference;
+    r.t = std::abs(mean - reference) * std::sqrt(sampleCount / std::max(variance, 1e-5));
+    r.pvalue = 2 * (1 - studentsTCdf(r.t, sampleCount - 1));
+    r.alpha = 1.0 - std::pow(1.0 - significanceLevel, 1.0 / numTests);          // Sidak correction
+    r.passed = !(r.pvalue < r.alpha || !std::isfinite(r.pvalue));
+    return r;
+}
+
+bool StudentsTTest::s_runOnActivate = true;
+StudentsTTest::StudentsTTest(const PropertyList &p) {
+    m_significanceLevel = p.getFloat("significanceLevel", 0.01f);
+    for (auto &a : tokenize(p.getString("angles", ""))) m_angles.push_back(toFloat(a));
+    for (auto &a : tokenize(p.getString("references", ""))) m_references.push_back(toFloat(a));
+    m_sampleCount = p.getInteger("sampleCount", 100000);
+}
+StudentsTTest::~StudentsTTest() { for (auto s : m_scenes) delete s; for (auto b : m_bsdfs) delete b; }
+void StudentsTTest::addChild(NoriObject *obj) {
+    switch (obj->getClassType()) {
+        case EBSDF: m_bsdfs.push_back(static_cast<BSDF *>(obj)); break;
+        case EScene: m_scenes.push_back(static_cast<Scene *>(obj)); break;
+        default: throw NoriException::format("StudentsTTest::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
+    }
+}
+TTestResult StudentsTTest::runScene(size_t i) {
+    Scene *scene = m_scenes.at(i);
+    GpuIntegrator *gi = dynamic_cast<GpuIntegrator *>(scene->getIntegrator());
+    if (!gi) throw NoriException("StudentsTTest: the scene's integrator has no GPU backend");
+    if (!gi->context()) gi->preprocess(scene);
+    // 100000 paths through the whole-image camera: pixelSample = next2D() * outputSize (src/ttest.cpp:171-173).
+    // Path k owns the stream pcg32.seed(k, scene index) instead of sharing one sampler.
+    const size_t n = (size_t) m_sampleCount;
+    std::vector<uint64_t> st(n), sq(n, (uint64_t) i); for (size_t k = 0; k < n; ++k) st[k] = k;
+    std::vector<float> rgb(3 * n);
+    hipCheck(nori_hip_li_samples(gi->context(), n, nullptr, nullptr, st.data(), sq.data(), nullptr, rgb.data()), "nori_hip_li_samples");
+    double mean = 0, variance = 0;
+    for (size_t k = 0; k < n; ++k) {        // Knuth's online variance, as the reference (src/ttest.cpp:178-184)
+        double result = (double) (rgb[3 * k] * 0.212671f + rgb[3 * k + 1] * 0.715160f + rgb[3 * k + 2] * 0.072169f);
+        double delta = result - mean; mean += delta / (double) (k + 1); variance += delta * (result - mean);
+    }
+    variance /= m_sampleCount - 1;
+    return studentsTTest(mean, variance, m_references.at(i), m_sampleCount, m_significanceLevel, (int) m_references.size());
+}
+void StudentsTTest::activate() {
+    if (!m_bsdfs.empty()) throw NoriException("StudentsTTest: BSDF-mode tests are not part of the path_mis hot path in this build");
+    if (m_references.size() != m_scenes.size()) throw NoriException("Specified a different number of scenes and reference values!");
+    if (!s_runOnActivate) return;
+    int passed = 0;
+    for (size_t i = 0; i < m_scenes.size(); ++i) {
+        TTestResult r = runScene(i);
+        m_results.push_back(r);
+        std::cout << "------------------------------------------------------\n"
+                  << "Sample mean = " << r.mean << " (reference value = " << r.reference << ")\nSample variance = " << r.variance
+                  << "\nt-statistic = " << r.t << " (d.o.f. = " << m_sampleCount - 1 << ")\n"
+                  << (r.passed ? "Accepted" : "***** Rejected *****") << " the null hypothesis (p-value = " << r.pvalue << ", significance level = " << r.alpha << ")" << std::endl;
+        if (r.passed) ++passed;
+    }
+    std::cout << "Passed " << passed << "/" << m_scenes.size() << " tests." << std::endl;
+}
+std::string StudentsTTest::toString() const { char b[128]; snprintf(b, sizeof(b), "StudentsTTest[\n  significanceLevel = %f,\n  sampleCount= %i\n]", m_significanceLevel, m_sampleCount); return b; }
+NORI_REGISTER_CLASS(StudentsTTest, "ttest")
+
+// ---- headless render driver (src/render.cpp:103-214 without the GUI thread) --------------------------------
+void writePFM(const std::string &path, const std::vector<float> &rgb, int w, int h) {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw NoriException::format("Unable to write \"%s\"", path.c_str());
+    f << "PF\n" << w << " " << h << "\n-1.0\n";
+    for (int y = h - 1; y >= 0; --y) f.write(reinterpret_cast<const char *>(&rgb[(size_t) y * w * 3]), (std::streamsize) w * 3 * 4);
+}
+
+std::string renderScene(const std::string &filename, int passSize) {
+    size_t slash = filename.find_last_of('/');
+    getFileResolver()->prepend(slash == std::string::npos ? std::string(".") : filename.substr(0, slash));
+    std::unique_ptr<NoriObject> root(loadFromXML(filename));
+    if (root->getClassType() != NoriObject::EScene) return std::string();
+    Scene *scene = static_cast<Scene *>(root.get());
+    scene->getIntegrator()->preprocess(scene);
+    const int spp = (int) scene->getSampler()->getSampleCount();
+    if (passSize <= 0) passSize = spp;
+    for (int k = 0; k < spp; k += passSize) scene->getIntegrator()->render(scene, k, std::min(spp, k + passSize));
+    std::vector<float> rgb; scene->getIntegrator()->readBitmap(rgb);
+    std::string out = filename; size_t dot = out.find_last_of('.'); if (dot != std::string::npos) out.erase(dot); out += ".pfm";
+    writePFM(out, rgb, scene->getCamera()->getWidth(), scene->getCamera()->getHeight());
+    return out;
+}
+
+} // namespace nori

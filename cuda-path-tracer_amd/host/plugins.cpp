@@ -1,0 +1,305 @@
+// The plugins the path_mis hot path needs, registered under the reference's names.
+// Reference: src/obj.cpp, src/mesh.cpp, src/sphere.cpp, src/shape.cpp, src/diffuse.cpp, src/microfacet.cpp,
+//            src/dielectric.cpp, src/mirror.cpp, src/arealight.cpp, src/perspective.cpp, src/independent.cpp,
+//            src/rfilter.cpp, src/scene.cpp, src/consttexture.cpp.
+#include "scene.h"
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <unordered_map>
+#include <iostream>
+#include <algorithm>
+
+namespace nori {
+
+// ---- Shape ------------------------------------------------------------------------------------------------
+Shape::~Shape() { delete m_bsdf; }
+void Shape::activate() {
+    if (!m_bsdf) { m_bsdf = static_cast<BSDF *>(NoriObjectFactory::createInstance("diffuse", PropertyList())); m_bsdf->activate(); }
+}
+void Shape::addChild(NoriObject *obj) {
+    switch (obj->getClassType()) {
+        case EBSDF:
+            if (m_bsdf) throw NoriException("Shape: tried to register multiple BSDF instances!");
+            m_bsdf = static_cast<BSDF *>(obj); break;
+        case EEmitter:
+            if (m_emitter) throw NoriException("Shape: tried to register multiple Emitter instances!");
+            m_emitter = static_cast<Emitter *>(obj); m_emitter->setShape(this); break;
+        default:
+            throw NoriException::format("Shape::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
+    }
+}
+
+// ---- Mesh -------------------------------------------------------------------------------------------------
+float Mesh::surfaceArea(uint32_t i) const {
+    Point3f p0 = vertex(m_F[3 * i]), p1 = vertex(m_F[3 * i + 1]), p2 = vertex(m_F[3 * i + 2]);
+    return 0.5f * norm(cross(p1 - p0, p2 - p0));
+}
+BoundingBox3f Mesh::getBoundingBox(uint32_t i) const {
+    BoundingBox3f r(vertex(m_F[3 * i])); r.expandBy(vertex(m_F[3 * i + 1])); r.expandBy(vertex(m_F[3 * i + 2])); return r;
+}
+Point3f Mesh::getCentroid(uint32_t i) const {
+    return (1.0f / 3.0f) * ((vertex(m_F[3 * i]) + vertex(m_F[3 * i + 1])) + vertex(m_F[3 * i + 2]));
+}
+void Mesh::activate() {
+    Shape::activate();
+    // DiscretePDF over triangle areas: running fp32 sum, then normalise and pin the last entry to 1 (include/nori/dpdf.h:55-57,97-109)
+    uint32_t n = getPrimitiveCount();
+    m_cdf.assign(1, 0.0f); m_cdf.reserve(n + 1);
+    for (uint32_t i = 0; i < n; ++i) m_cdf.push_back(m_cdf.back() + surfaceArea(i));
+    float sum = m_cdf.back();
+    if (sum > 0) { m_cdfNorm = 1.0f / sum; for (size_t i = 1; i < m_cdf.size(); ++i) m_cdf[i] *= m_cdfNorm; m_cdf.back() = 1.0f; }
+    else m_cdfNorm = 0.0f;
+}
+std::string Mesh::toString() const {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "Mesh[\n  name = \"%s\",\n  vertexCount = %zu,\n  triangleCount = %zu,\n  bsdf = %s,\n  emitter = %s\n]", m_name.c_str(),
+             m_V.size() / 3, m_F.size() / 3, m_bsdf ? indent(m_bsdf->toString()).c_str() : "null", m_emitter ? indent(m_emitter->toString()).c_str() : "null");
+    return buf;
+}
+
+/// Wavefront OBJ loader (src/obj.cpp:32-132): v/vt/vn/f, toWorld applied at load, quads split (0,1,2),(3,0,2),
+/// vertices de-duplicated on the (p, uv, n) index triple in order of first use.
+class WavefrontOBJ : public Mesh {
+public:
+    explicit WavefrontOBJ(const PropertyList &propList) {
+        std::string filename = getFileResolver()->resolve(propList.getString("filename"));
+        std::ifstream is(filename);
+        if (is.fail()) throw NoriException::format("Unable to open OBJ file \"%s\"!", filename.c_str());
+        Transform trafo = propList.getTransform("toWorld", Transform());
+        struct Key { uint32_t p, n, uv; bool operator==(const Key &o) const { return p == o.p && n == o.n && uv == o.uv; } };
+        struct KeyHash { size_t operator()(const Key &k) const { size_t h = k.p; h = h * 37 + k.uv; h = h * 37 + k.n; return h; } };
+        std::vector<Point3f> positions, normals; std::vector<Point2f> texcoords; std::vector<Key> vertices;
+        std::unordered_map<Key, uint32_t, KeyHash> vertexMap;
+        auto parseVertex = [](const std::string &s) {
+            std::vector<std::string> tk = tokenize(s, "/", true);
+            if (tk.size() < 1 || tk.size() > 3) throw NoriException::format("Invalid vertex data: \"%s\"", s.c_str());
+            Key k{(uint32_t) -1, (uint32_t) -1, (uint32_t) -1};
+            k.p = toUInt(tk[0]);
+            if (tk.size() >= 2 && !tk[1].empty()) k.uv = toUInt(tk[1]);
+            if (tk.size() >= 3 && !tk[2].empty()) k.n = toUInt(tk[2]);
+            return k;
+        };
+        std::string line_str;
+        while (std::getline(is, line_str)) {
+            std::istringstream line(line_str);
+            std::string prefix; line >> prefix;
+            if (prefix == "v") { Point3f p; line >> p.x >> p.y >> p.z; p = trafo.point(p); m_bbox.expandBy(p); positions.push_back(p); }
+            else if (prefix == "vt") { Point2f tc; line >> tc.x >> tc.y; texcoords.push_back(tc); }
+            else if (prefix == "vn") { Normal3f n; line >> n.x >> n.y >> n.z; normals.push_back(normalized(trafo.normal(n))); }
+            else if (prefix == "f") {
+                std::string v[4]; line >> v[0] >> v[1] >> v[2] >> v[3];
+                Key verts[6]; int nV = 3;
+                for (int i = 0; i < 3; ++i) verts[i] = parseVertex(v[i]);
+                if (!v[3].empty()) { verts[3] = parseVertex(v[3]); verts[4] = verts[0]; verts[5] = verts[2]; nV = 6; }
+                for (int i = 0; i < nV; ++i) {
+                    auto it = vertexMap.find(verts[i]);
+                    if (it == vertexMap.end()) { uint32_t id = (uint32_t) vertices.size(); vertexMap[verts[i]] = id; m_F.push_back(id); vertices.push_back(verts[i]); }
+                    else m_F.push_back(it->second);
+                }
+            }
+        }
+        m_V.resize(3 * vertices.size());
+        for (size_t i = 0; i < vertices.size(); ++i) { const Point3f &p = positions.at(vertices[i].p - 1); m_V[3 * i] = p.x; m_V[3 * i + 1] = p.y; m_V[3 * i + 2] = p.z; }
+        if (!normals.empty()) { m_N.resize(3 * vertices.size());
+            for (size_t i = 0; i < vertices.size(); ++i) { const Normal3f &n = normals.at(vertices[i].n - 1); m_N[3 * i] = n.x; m_N[3 * i + 1] = n.y; m_N[3 * i + 2] = n.z; } }
+        if (!texcoords.empty()) { m_UV.resize(2 * vertices.size());
+            for (size_t i = 0; i < vertices.size(); ++i) { const Point2f &t = texcoords.at(vertices[i].uv - 1); m_UV[2 * i] = t.x; m_UV[2 * i + 1] = t.y; } }
+        m_name = filename;
+    }
+};
+NORI_REGISTER_CLASS(WavefrontOBJ, "obj")
+
+/// Mesh handed over as arrays by the embedding program (procedural scenes, e.g. the 10M-triangle stress mesh)
+class ArrayMesh : public Mesh {
+public:
+    explicit ArrayMesh(const PropertyList &) {}
+    void set(const std::string &name, const float *V, size_t nV, const uint32_t *F, size_t nF, const float *N, const float *UV) {
+        m_name = name; m_V.assign(V, V + 3 * nV); m_F.assign(F, F + 3 * nF);
+        if (N) m_N.assign(N, N + 3 * nV); if (UV) m_UV.assign(UV, UV + 2 * nV);
+        for (size_t i = 0; i < nV; ++i) m_bbox.expandBy(vertex((uint32_t) i));
+    }
+};
+NORI_REGISTER_CLASS(ArrayMesh, "array_mesh")
+void arrayMeshSet(Mesh *m, const std::string &name, const float *V, size_t nV, const uint32_t *F, size_t nF, const float *N, const float *UV) {
+    static_cast<ArrayMesh *>(m)->set(name, V, nV, F, nF, N, UV);
+}
+
+// ---- Sphere -----------------------------------------------------------------------------------------------
+Sphere::Sphere(const PropertyList &propList) {
+    m_position = propList.getPoint3("center", Point3f()); m_radius = propList.getFloat("radius", 1.f);
+    m_bbox.expandBy(m_position - Vector3f(m_radius)); m_bbox.expandBy(m_position + Vector3f(m_radius));
+}
+std::string Sphere::toString() const { char b[256]; snprintf(b, sizeof(b), "Sphere[\n  center = [%f, %f, %f],\n  radius = %f\n]", m_position.x, m_position.y, m_position.z, m_radius); return b; }
+NORI_REGISTER_CLASS(Sphere, "sphere")
+
+// ---- BSDFs ------------------------------------------------------------------------------------------------
+static std::string colorStr(const Color3f &c) { char b[96]; snprintf(b, sizeof(b), "[%f, %f, %f]", c.x, c.y, c.z); return b; }
+
+/// constant_color texture: the only texture the CPU reference can evaluate without OpenCV (src/consttexture.cpp)
+class ConstantColorTexture : public NoriObject {
+public:
+    explicit ConstantColorTexture(const PropertyList &p) { m_value = p.getColor("value", Color3f(0.f)); }
+    EClassType getClassType() const override { return ETexture; }
+    Color3f eval(const Point2f &) const { return m_value; }
+    std::string toString() const override { return "ConstantTexture[ " + colorStr(m_value) + " ]"; }
+private:
+    Color3f m_value;
+};
+NORI_REGISTER_CLASS(ConstantColorTexture, "constant_color")
+
+class Diffuse : public BSDF {
+public:
+    explicit Diffuse(const PropertyList &propList) { if (propList.has("albedo")) { m_albedo = propList.getColor("albedo"); m_has = true; } }
+    void addChild(NoriObject *obj) override {
+        if (obj->getClassType() != ETexture) throw NoriException::format("Diffuse::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
+        if (obj->getIdName() != "albedo") throw NoriException("The name of this texture does not match any field!");
+        if (m_has) throw NoriException("There is already an albedo defined!");
+        ConstantColorTexture *t = dynamic_cast<ConstantColorTexture *>(obj);
+        if (!t) throw NoriException("Diffuse: only constant_color albedo textures are supported by this build");
+        m_albedo = t->eval(Point2f()); m_has = true; delete obj;
+    }
+    void activate() override { if (!m_has) { m_albedo = Color3f(0.5f); m_has = true; } }
+    bool isDelta() const override { return false; }
+    void describe(NoriHipShape &o) const override { o.bsdf = NORI_HIP_BSDF_DIFFUSE; o.albedo[0] = m_albedo.x; o.albedo[1] = m_albedo.y; o.albedo[2] = m_albedo.z; }
+    std::string toString() const override { return "Diffuse[\n  albedo = ConstantTexture[ " + colorStr(m_albedo) + " ]\n]"; }
+private:
+    Color3f m_albedo; bool m_has = false;
+};
+NORI_REGISTER_CLASS(Diffuse, "diffuse")
+
+class Microfacet : public BSDF {
+public:
+    explicit Microfacet(const PropertyList &p) {
+        m_alpha = p.getFloat("alpha", 0.1f); m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f);
+        m_kd = p.getColor("kd", Color3f(0.5f)); m_ks = 1 - std::max(m_kd.x, std::max(m_kd.y, m_kd.z));
+    }
+    bool isDelta() const override { return false; }
+    void describe(NoriHipShape &o) const override {
+        o.bsdf = NORI_HIP_BSDF_MICROFACET; o.albedo[0] = m_kd.x; o.albedo[1] = m_kd.y; o.albedo[2] = m_kd.z;
+        o.alpha = m_alpha; o.int_ior = m_intIOR; o.ext_ior = m_extIOR; o.ks = m_ks;
+    }
+    std::string toString() const override { char b[256]; snprintf(b, sizeof(b), "Microfacet[\n  alpha = %f,\n  intIOR = %f,\n  extIOR = %f,\n  kd = %s,\n  ks = %f\n]", m_alpha, m_intIOR, m_extIOR, colorStr(m_kd).c_str(), m_ks); return b; }
+private:
+    float m_alpha, m_intIOR, m_extIOR, m_ks; Color3f m_kd;
+};
+NORI_REGISTER_CLASS(Microfacet, "microfacet")
+
+class Dielectric : public BSDF {
+public:
+    explicit Dielectric(const PropertyList &p) { m_intIOR = p.getFloat("intIOR", 1.5046f); m_extIOR = p.getFloat("extIOR", 1.000277f); }
+    bool isDelta() const override { return true; }
+    void describe(NoriHipShape &o) const override { o.bsdf = NORI_HIP_BSDF_DIELECTRIC; o.int_ior = m_intIOR; o.ext_ior = m_extIOR; }
+    std::string toString() const override { char b[128]; snprintf(b, sizeof(b), "Dielectric[\n  intIOR = %f,\n  extIOR = %f\n]", m_intIOR, m_extIOR); return b; }
+private:
+    float m_intIOR, m_extIOR;
+};
+NORI_REGISTER_CLASS(Dielectric, "dielectric")
+
+class Mirror : public BSDF {
+public:
+    explicit Mirror(const PropertyList &) {}
+    bool isDelta() const override { return true; }
+    void describe(NoriHipShape &o) const override { o.bsdf = NORI_HIP_BSDF_MIRROR; }
+    std::string toString() const override { return "Mirror[]"; }
+};
+NORI_REGISTER_CLASS(Mirror, "mirror")
+
+// ---- area emitter -----------------------------------------------------------------------------------------
+class AreaEmitter : public Emitter {
+public:
+    explicit AreaEmitter(const PropertyList &p) { m_radiance = p.getColor("radiance"); }
+    Color3f getRadiance() const override { return m_radiance; }
+    std::string toString() const override { return "AreaLight[\n  radiance = " + colorStr(m_radiance) + ",\n]"; }
+private:
+    Color3f m_radiance;
+};
+NORI_REGISTER_CLASS(AreaEmitter, "area")
+
+// ---- reconstruction filters (radius only: the film's border size; src/rfilter.cpp:43-135) ------------------
+class GaussianFilter : public ReconstructionFilter { public: explicit GaussianFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); m_stddev = p.getFloat("stddev", 0.5f); }
+    std::string toString() const override { char b[96]; snprintf(b, sizeof(b), "GaussianFilter[radius=%f, stddev=%f]", m_radius, m_stddev); return b; } float m_stddev; };
+class MitchellNetravaliFilter : public ReconstructionFilter { public: explicit MitchellNetravaliFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); }
+    std::string toString() const override { return "MitchellNetravaliFilter[]"; } };
+class TentFilter : public ReconstructionFilter { public: explicit TentFilter(const PropertyList &) { m_radius = 1.0f; } std::string toString() const override { return "TentFilter[]"; } };
+class BoxFilter : public ReconstructionFilter { public: explicit BoxFilter(const PropertyList &) { m_radius = 0.5f; } std::string toString() const override { return "BoxFilter[]"; } };
+NORI_REGISTER_CLASS(GaussianFilter, "gaussian")
+NORI_REGISTER_CLASS(MitchellNetravaliFilter, "mitchell")
+NORI_REGISTER_CLASS(TentFilter, "tent")
+NORI_REGISTER_CLASS(BoxFilter, "box")
+
+// ---- camera -----------------------------------------------------------------------------------------------
+class PerspectiveCamera : public Camera {
+public:
+    explicit PerspectiveCamera(const PropertyList &p) {
+        m_width = p.getInteger("width", 1280); m_height = p.getInteger("height", 720);
+        m_cameraToWorld = p.getTransform("toWorld", Transform());
+        m_fov = p.getFloat("fov", 30.0f); m_nearClip = p.getFloat("nearClip", 1e-4f); m_farClip = p.getFloat("farClip", 1e4f);
+    }
+    ~PerspectiveCamera() override { delete m_rfilter; }
+    void addChild(NoriObject *obj) override {
+        if (obj->getClassType() != EReconstructionFilter) throw NoriException::format("Camera::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
+        if (m_rfilter) throw NoriException("Camera: tried to register multiple reconstruction filters!");
+        m_rfilter = static_cast<ReconstructionFilter *>(obj);
+    }
+    void activate() override {
+        // src/perspective.cpp:53-80: sampleToCamera = (Diag(0.5, -0.5*aspect, 1) * Translate(1, -1/aspect, 0) * perspective)^-1
+        float aspect = m_width / (float) m_height;
+        float recip = 1.0f / (m_farClip - m_nearClip), cot = 1.0f / std::tan(degToRad(m_fov / 2.0f));
+        float persp[4][4] = {{cot, 0, 0, 0}, {0, cot, 0, 0}, {0, 0, m_farClip * recip, -m_nearClip * m_farClip * recip}, {0, 0, 1, 0}};
+        float sx = 0.5f, sy = -0.5f * aspect, sz = 1.0f, tx = 1.0f, ty = -1.0f / aspect, tz = 0.0f;
+        float st[4][4] = {{sx, 0, 0, sx * tx}, {0, sy, 0, sy * ty}, {0, 0, sz, sz * tz}, {0, 0, 0, 1}};
+        float prod[4][4];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = st[i][0] * persp[0][j]; for (int k = 1; k < 4; ++k) s += st[i][k] * persp[k][j]; prod[i][j] = s; }
+        m_sampleToCamera = Transform(prod).inverse();
+        if (!m_rfilter) { m_rfilter = static_cast<ReconstructionFilter *>(NoriObjectFactory::createInstance("gaussian", PropertyList())); m_rfilter->activate(); }
+    }
+    void describe(NoriHipCamera &o) const override {
+        std::memcpy(o.sample_to_camera, m_sampleToCamera.m, 64); std::memcpy(o.camera_to_world, m_cameraToWorld.m, 64);
+        o.width = m_width; o.height = m_height; o.near_clip = m_nearClip; o.far_clip = m_farClip; o.filter_radius = m_rfilter->getRadius();
+    }
+    std::string toString() const override { char b[256]; snprintf(b, sizeof(b), "PerspectiveCamera[\n  outputSize = [%d, %d],\n  fov = %f,\n  clip = [%f, %f],\n  rfilter = %s\n]", m_width, m_height, m_fov, m_nearClip, m_farClip, m_rfilter ? m_rfilter->toString().c_str() : "null"); return b; }
+private:
+    Transform m_sampleToCamera, m_cameraToWorld; float m_fov, m_nearClip, m_farClip;
+};
+NORI_REGISTER_CLASS(PerspectiveCamera, "perspective")
+
+// ---- sampler ----------------------------------------------------------------------------------------------
+/// "independent": pcg32 streams.  On the GPU path every camera sample owns its stream:
+/// pcg32.seed(initstate = y*width + x, initseq = sample index); the draw order within a sample is the reference's.
+class Independent : public Sampler {
+public:
+    explicit Independent(const PropertyList &p) { m_sampleCount = (size_t) p.getInteger("sampleCount", 1); }
+    std::string toString() const override { char b[64]; snprintf(b, sizeof(b), "Independent[sampleCount=%zu]", m_sampleCount); return b; }
+};
+NORI_REGISTER_CLASS(Independent, "independent")
+
+// ---- scene ------------------------------------------------------------------------------------------------
+Scene::Scene(const PropertyList &) { m_bvh = new BVH(); }
+Scene::~Scene() { delete m_bvh; delete m_sampler; delete m_camera; delete m_integrator; for (auto e : m_emitters) delete e; }
+void Scene::activate() {
+    m_bvh->build();
+    if (!m_integrator) throw NoriException("No integrator was specified!");
+    if (!m_camera) throw NoriException("No camera was specified!");
+    if (!m_sampler) { m_sampler = static_cast<Sampler *>(NoriObjectFactory::createInstance("independent", PropertyList())); m_sampler->activate(); }
+}
+void Scene::addChild(NoriObject *obj) {
+    switch (obj->getClassType()) {
+        case EMesh: { Shape *mesh = static_cast<Shape *>(obj); m_bvh->addShape(mesh); m_shapes.push_back(mesh); if (mesh->isEmitter()) m_emitters.push_back(mesh->getEmitter()); } break;
+        case EEmitter: m_emitters.push_back(static_cast<Emitter *>(obj)); break;
+        case ESampler: if (m_sampler) throw NoriException("There can only be one sampler per scene!"); m_sampler = static_cast<Sampler *>(obj); break;
+        case ECamera: if (m_camera) throw NoriException("There can only be one camera per scene!"); m_camera = static_cast<Camera *>(obj); break;
+        case EIntegrator: if (m_integrator) throw NoriException("There can only be one integrator per scene!"); m_integrator = static_cast<Integrator *>(obj); break;
+        default: throw NoriException::format("Scene::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
+    }
+}
+std::string Scene::toString() const {
+    std::string shapes, lights;
+    for (size_t i = 0; i < m_shapes.size(); ++i) { shapes += "  " + indent(m_shapes[i]->toString(), 2); if (i + 1 < m_shapes.size()) shapes += ","; shapes += "\n"; }
+    for (size_t i = 0; i < m_emitters.size(); ++i) { lights += "  " + indent(m_emitters[i]->toString(), 2); if (i + 1 < m_emitters.size()) lights += ","; lights += "\n"; }
+    return "Scene[\n  integrator = " + indent(m_integrator->toString()) + ",\n  sampler = " + indent(m_sampler->toString()) + "\n  camera = " + indent(m_camera->toString()) +
+           ",\n  shapes = {\n  " + indent(shapes, 2) + "  }\n  emitters = {\n  " + indent(lights, 2) + "  }\n]";
+}
+NORI_REGISTER_CLASS(Scene, "scene")
+
+} // namespace nori

@@ -1,0 +1,369 @@
+"""ctypes bindings of the MI355X path_mis renderer.
+
+Two in-tree shared libraries are bound here, nothing else:
+  libnori_hip.so   gfx950 kernels behind the device C ABI (include/nori_hip.h)
+  libnori_host.so  Nori's host plugin surface (include/nori_host.h)
+There is no CPU fallback: if the libraries are missing or no GPU is present, calls raise NoriHipError.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class NoriHipError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    _fields_ = [("sample_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16), ("width", C.c_int32), ("height", C.c_int32),
+                ("near_clip", C.c_float), ("far_clip", C.c_float), ("filter_radius", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("nodes", C.c_void_p), ("n_prims", C.c_uint32), ("prims", C.c_void_p), ("shade_prims", C.c_void_p),
+                ("root", C.c_uint32), ("root_min", C.c_float * 3), ("root_max", C.c_float * 3),
+                ("n_shapes", C.c_uint32), ("shapes", C.c_void_p), ("n_emitters", C.c_uint32), ("emitters", C.c_void_p),
+                ("n_cdf", C.c_uint32), ("cdf", C.c_void_p), ("n_light_prims", C.c_uint32), ("light_prims", C.c_void_p), ("camera", Camera)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("camera_samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("invalid_samples", C.c_uint64),
+                ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint64), ("render_ms", C.c_double),
+                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double)]
+
+
+NODE_DTYPE = np.dtype([("lmin", "<f4", 3), ("lmax", "<f4", 3), ("rmin", "<f4", 3), ("rmax", "<f4", 3), ("left", "<u4"), ("right", "<u4"),
+                       ("lcount", "<u4"), ("rcount", "<u4")])
+PRIM_DTYPE = np.dtype([("a", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("prim", "<u4"), ("shape_flags", "<u4"), ("pad", "<u4")])
+SHADE_DTYPE = np.dtype([("p0", "<f4", 3), ("p1", "<f4", 3), ("p2", "<f4", 3), ("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
+                        ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("uv2", "<f4", 2)])
+SHAPE_DTYPE = np.dtype([("type", "<i4"), ("bsdf", "<i4"), ("emitter", "<i4"), ("flags", "<u4"), ("albedo", "<f4", 3), ("alpha", "<f4"),
+                        ("int_ior", "<f4"), ("ext_ior", "<f4"), ("ks", "<f4"), ("center", "<f4", 3), ("radius", "<f4"), ("pad", "<u4")])
+EMITTER_DTYPE = np.dtype([("radiance", "<f4", 3), ("shape", "<i4"), ("cdf_offset", "<u4"), ("n_tris", "<u4"), ("light_prim_offset", "<u4"),
+                          ("area_pdf", "<f4")])
+NODE32_DTYPE = np.dtype([("w0", "<u4"), ("w1", "<u4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3)])
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("mint", "<f4"), ("d", "<f4", 3), ("maxt", "<f4")])
+HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+assert NODE_DTYPE.itemsize == 64 and PRIM_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 96 and SHAPE_DTYPE.itemsize == 64 and EMITTER_DTYPE.itemsize == 32
+
+MISS = 0xFFFFFFFF
+_hip = None
+_host = None
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def hip_lib():
+    """libnori_hip.so; raises if it is not built"""
+    global _hip
+    if _hip is None:
+        p = os.path.join(_PKG, "libnori_hip.so")
+        if not os.path.exists(p):
+            raise NoriHipError("libnori_hip.so is not built: run __graft_entry__.build() or `make -C cuda-path-tracer_amd`")
+        L = C.CDLL(p, mode=C.RTLD_GLOBAL)
+        L.nori_hip_last_error.restype = C.c_char_p
+        vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+        L.nori_hip_create.argtypes = [i32, C.POINTER(vp)]
+        L.nori_hip_destroy.argtypes = [vp]
+        L.nori_hip_upload_scene.argtypes = [vp, vp]
+        L.nori_hip_trace.argtypes = [vp, vp, sz, i32, vp, vp]
+        L.nori_hip_trace_device.argtypes = [vp, vp, sz, i32, vp]
+        L.nori_hip_camera_rays.argtypes = [vp, vp, sz, vp]
+        L.nori_hip_li_samples.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
+        L.nori_hip_render.argtypes = [vp, i32, i32, i32, i32, i32, i32]
+        L.nori_hip_clear_film.argtypes = [vp]
+        L.nori_hip_film_dims.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.nori_hip_read_film.argtypes = [vp, vp]
+        L.nori_hip_write_film.argtypes = [vp, vp]
+        L.nori_hip_film_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+        L.nori_hip_read_bitmap.argtypes = [vp, vp]
+        L.nori_hip_filter.argtypes = [vp, i32, i32, C.c_float, C.c_float, vp]
+        L.nori_hip_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.nori_hip_reset_stats.argtypes = [vp]
+        L.nori_hip_stream.argtypes = [vp, C.POINTER(vp)]
+        L.nori_hip_synchronize.argtypes = [vp]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        hip_lib()
+        p = os.path.join(_PKG, "libnori_host.so")
+        if not os.path.exists(p):
+            raise NoriHipError("libnori_host.so is not built: run __graft_entry__.build() or `make -C cuda-path-tracer_amd`")
+        L = C.CDLL(p)
+        vp, i32 = C.c_void_p, C.c_int
+        L.nori_host_last_error.restype = C.c_char_p
+        L.nori_host_load.restype = vp
+        L.nori_host_load.argtypes = [C.c_char_p, i32, i32, i32]
+        L.nori_host_free.argtypes = [vp]
+        L.nori_host_is_test.argtypes = [vp]
+        L.nori_host_scene_count.argtypes = [vp]
+        L.nori_host_scene_begin.restype = vp
+        L.nori_host_scene_add_mesh.argtypes = [vp, C.c_char_p, vp, C.c_size_t, vp, C.c_size_t, vp, vp, C.c_char_p, vp, C.c_float, C.c_float, C.c_float, vp]
+        L.nori_host_scene_set_camera.argtypes = [vp, vp, vp, vp, C.c_float, i32, i32]
+        L.nori_host_scene_end.argtypes = [vp, i32, i32]
+        L.nori_host_info.argtypes = [vp, i32, vp]
+        L.nori_host_bvh_build_seconds.restype = C.c_double
+        L.nori_host_bvh_build_seconds.argtypes = [vp, i32]
+        L.nori_host_bvh32.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32)]
+        L.nori_host_mesh.argtypes = [vp, i32, i32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        L.nori_host_flatten.restype = C.POINTER(SceneDesc)
+        L.nori_host_flatten.argtypes = [vp, i32]
+        L.nori_host_preprocess.argtypes = [vp, i32, i32]
+        L.nori_host_context.restype = vp
+        L.nori_host_context.argtypes = [vp, i32]
+        L.nori_host_render.argtypes = [vp, i32, i32, i32]
+        L.nori_host_test_meta.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(i32)]
+        L.nori_host_test_run.argtypes = [vp, i32, vp]
+        L.nori_host_render_file.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        _host = L
+    return _host
+
+
+def _hchk(rc):
+    if rc != 0:
+        raise NoriHipError(hip_lib().nori_hip_last_error().decode())
+
+
+def _ochk(rc):
+    if rc < 0:
+        raise NoriHipError(host_lib().nori_host_last_error().decode())
+
+
+def _from_ptr(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class Context:
+    """One NoriHipContext (one GPU).  Thin, allocation-free view over the device C ABI."""
+
+    def __init__(self, handle=None, device=0, owned=True):
+        self.L = hip_lib()
+        self.owned = owned
+        if handle is None:
+            h = C.c_void_p()
+            _hchk(self.L.nori_hip_create(device, C.byref(h)))
+            handle = h.value
+        self.h = C.c_void_p(handle)
+
+    def close(self):
+        if self.owned and self.h:
+            self.L.nori_hip_destroy(self.h)
+        self.h = None
+
+    def upload(self, desc_ptr):
+        _hchk(self.L.nori_hip_upload_scene(self.h, C.cast(desc_ptr, C.c_void_p)))
+
+    def trace(self, rays, any_hit=False, full=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        fu = np.zeros((len(rays), 16), np.float32) if full else None
+        _hchk(self.L.nori_hip_trace(self.h, _vp(rays), len(rays), int(any_hit), _vp(hits), _vp(fu)))
+        return (hits, fu) if full else hits
+
+    def camera_rays(self, pixel_samples):
+        ps = np.ascontiguousarray(pixel_samples, np.float32).reshape(-1, 2)
+        rays = np.zeros((len(ps), 8), np.float32)
+        _hchk(self.L.nori_hip_camera_rays(self.h, _vp(ps), len(ps), _vp(rays)))
+        return rays
+
+    def li_samples(self, states, seqs, px=None, py=None, rays=None):
+        st = np.ascontiguousarray(states, np.uint64)
+        sq = np.ascontiguousarray(seqs, np.uint64)
+        n = len(st)
+        px = None if px is None else np.ascontiguousarray(px, np.int32)
+        py = None if py is None else np.ascontiguousarray(py, np.int32)
+        rays = None if rays is None else np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        rgb = np.zeros((n, 3), np.float32)
+        _hchk(self.L.nori_hip_li_samples(self.h, n, _vp(px), _vp(py), _vp(st), _vp(sq), _vp(rays), _vp(rgb)))
+        return rgb
+
+    def render(self, spp_begin, spp_end, tile=None):
+        if tile is None:
+            rows, cols, b = self.film_dims()
+            tile = (0, 0, cols - 2 * b, rows - 2 * b)
+        _hchk(self.L.nori_hip_render(self.h, tile[0], tile[1], tile[2], tile[3], spp_begin, spp_end))
+
+    def clear_film(self):
+        _hchk(self.L.nori_hip_clear_film(self.h))
+
+    def film_dims(self):
+        r, c, b = C.c_int(), C.c_int(), C.c_int()
+        _hchk(self.L.nori_hip_film_dims(self.h, C.byref(r), C.byref(c), C.byref(b)))
+        return r.value, c.value, b.value
+
+    def read_film(self):
+        r, c, _ = self.film_dims()
+        f = np.zeros((r, c, 4), np.float32)
+        _hchk(self.L.nori_hip_read_film(self.h, _vp(f)))
+        return f
+
+    def write_film(self, film):
+        film = np.ascontiguousarray(film, np.float32)
+        _hchk(self.L.nori_hip_write_film(self.h, _vp(film)))
+
+    def film_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _hchk(self.L.nori_hip_film_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_bitmap(self):
+        r, c, b = self.film_dims()
+        img = np.zeros((r - 2 * b, c - 2 * b, 3), np.float32)
+        _hchk(self.L.nori_hip_read_bitmap(self.h, _vp(img)))
+        return img
+
+    def filter(self, r=3, f=10, sigma=0.5, h=0.002):
+        rows, cols, b = self.film_dims()
+        out = np.zeros((rows - 2 * b, cols - 2 * b, 3), np.float32)
+        _hchk(self.L.nori_hip_filter(self.h, r, f, sigma, h, _vp(out)))
+        return out
+
+    def stats(self):
+        s = Stats()
+        _hchk(self.L.nori_hip_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def reset_stats(self):
+        _hchk(self.L.nori_hip_reset_stats(self.h))
+
+    def stream(self):
+        p = C.c_void_p()
+        _hchk(self.L.nori_hip_stream(self.h, C.byref(p)))
+        return p.value
+
+    def synchronize(self):
+        _hchk(self.L.nori_hip_synchronize(self.h))
+
+
+class HostScene:
+    """A scene file (or <test> file) loaded through the host plugin surface."""
+
+    def __init__(self, xml=None, width=0, height=0, spp=0, handle=None):
+        self.L = host_lib()
+        if handle is None:
+            handle = self.L.nori_host_load(os.fspath(xml).encode(), width, height, spp)
+            if not handle:
+                raise NoriHipError(self.L.nori_host_last_error().decode())
+        self.h = C.c_void_p(handle)
+
+    def close(self):
+        if self.h:
+            self.L.nori_host_free(self.h)
+        self.h = None
+
+    @property
+    def is_test(self):
+        return bool(self.L.nori_host_is_test(self.h))
+
+    @property
+    def scene_count(self):
+        return self.L.nori_host_scene_count(self.h)
+
+    def info(self, scene=0):
+        out = np.zeros(8, np.int32)
+        _ochk(self.L.nori_host_info(self.h, scene, _vp(out)))
+        return dict(zip(["shapes", "prims", "emitters", "width", "height", "spp", "nodes", "wide_nodes"], [int(x) for x in out]))
+
+    def bvh_build_seconds(self, scene=0):
+        return self.L.nori_host_bvh_build_seconds(self.h, scene)
+
+    def bvh32(self, scene=0):
+        n, ni = C.c_uint32(), C.c_uint32()
+        pn, pi = C.c_void_p(), C.c_void_p()
+        _ochk(self.L.nori_host_bvh32(self.h, scene, C.byref(pn), C.byref(n), C.byref(pi), C.byref(ni)))
+        return _from_ptr(pn.value, n.value, NODE32_DTYPE), _from_ptr(pi.value, ni.value, np.uint32)
+
+    def mesh(self, shape, scene=0):
+        counts = np.zeros(4, np.int32)
+        V, N, UV, F, cdf = (C.c_void_p() for _ in range(5))
+        rc = self.L.nori_host_mesh(self.h, scene, shape, _vp(counts), C.byref(V), C.byref(N), C.byref(UV), C.byref(F), C.byref(cdf))
+        _ochk(rc)
+        if rc == 1:
+            return None
+        nV, nF, hasN, hasUV = [int(x) for x in counts]
+        return dict(V=_from_ptr(V.value, nV * 3, np.float32).reshape(-1, 3), N=_from_ptr(N.value, nV * 3, np.float32).reshape(-1, 3) if hasN else None,
+                    UV=_from_ptr(UV.value, nV * 2, np.float32).reshape(-1, 2) if hasUV else None,
+                    F=_from_ptr(F.value, nF * 3, np.uint32).reshape(-1, 3), cdf=_from_ptr(cdf.value, nF + 1, np.float32))
+
+    def flatten(self, scene=0):
+        d = self.L.nori_host_flatten(self.h, scene)
+        if not d:
+            raise NoriHipError(self.L.nori_host_last_error().decode())
+        return d
+
+    def tables(self, scene=0):
+        """numpy views of the flattened tables"""
+        d = self.flatten(scene).contents
+        return dict(desc=d, nodes=_from_ptr(d.nodes, d.n_nodes, NODE_DTYPE), prims=_from_ptr(d.prims, d.n_prims, PRIM_DTYPE),
+                    shade=_from_ptr(d.shade_prims, d.n_prims, SHADE_DTYPE), shapes=_from_ptr(d.shapes, d.n_shapes, SHAPE_DTYPE),
+                    emitters=_from_ptr(d.emitters, d.n_emitters, EMITTER_DTYPE), cdf=_from_ptr(d.cdf, d.n_cdf, np.float32),
+                    light_prims=_from_ptr(d.light_prims, d.n_light_prims, SHADE_DTYPE))
+
+    def preprocess(self, scene=0, device=-1):
+        _ochk(self.L.nori_host_preprocess(self.h, scene, device))
+        return self.context(scene)
+
+    def context(self, scene=0):
+        c = self.L.nori_host_context(self.h, scene)
+        if not c:
+            raise NoriHipError("no device context: preprocess() has not run (" + self.L.nori_host_last_error().decode() + ")")
+        return Context(handle=c, owned=False)
+
+    def render(self, spp_begin, spp_end, scene=0):
+        _ochk(self.L.nori_host_render(self.h, scene, spp_begin, spp_end))
+
+    def test_meta(self, scene):
+        ref, n, sig, pm = C.c_float(), C.c_int(), C.c_float(), C.c_int()
+        _ochk(self.L.nori_host_test_meta(self.h, scene, C.byref(ref), C.byref(n), C.byref(sig), C.byref(pm)))
+        return dict(reference=ref.value, n=n.value, significance=sig.value, path_mis=bool(pm.value))
+
+    def test_run(self, scene):
+        out = np.zeros(7, np.float64)
+        _ochk(self.L.nori_host_test_run(self.h, scene, _vp(out)))
+        return dict(zip(["mean", "variance", "reference", "t", "pvalue", "alpha", "passed"], out.tolist()))
+
+
+class SceneBuilder:
+    """Programmatic scene (procedural meshes) through the same plugin classes the parser instantiates."""
+
+    def __init__(self):
+        self.L = host_lib()
+        h = self.L.nori_host_scene_begin()
+        if not h:
+            raise NoriHipError(self.L.nori_host_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def add_mesh(self, name, V, F, N=None, UV=None, bsdf="diffuse", color=(0.5, 0.5, 0.5), alpha=0.1, int_ior=1.5046, ext_ior=1.000277, radiance=None):
+        V = np.ascontiguousarray(V, np.float32).reshape(-1, 3)
+        F = np.ascontiguousarray(F, np.uint32).reshape(-1, 3)
+        N = None if N is None else np.ascontiguousarray(N, np.float32)
+        UV = None if UV is None else np.ascontiguousarray(UV, np.float32)
+        col = np.asarray(color, np.float32)
+        rad = None if radiance is None else np.asarray(radiance, np.float32)
+        _ochk(self.L.nori_host_scene_add_mesh(self.h, name.encode(), _vp(V), len(V), _vp(F), len(F), _vp(N), _vp(UV), bsdf.encode(), _vp(col), alpha, int_ior,
+                                              ext_ior, _vp(rad)))
+
+    def set_camera(self, origin, target, up, fov, width, height):
+        o, t, u = (np.asarray(x, np.float32) for x in (origin, target, up))
+        _ochk(self.L.nori_host_scene_set_camera(self.h, _vp(o), _vp(t), _vp(u), fov, width, height))
+
+    def finish(self, spp=1, build_threads=0):
+        _ochk(self.L.nori_host_scene_end(self.h, spp, build_threads))
+        return HostScene(handle=self.h.value)
+
+
+def render_file(xml):
+    buf = C.create_string_buffer(4096)
+    _ochk(host_lib().nori_host_render_file(os.fspath(xml).encode(), buf, 4096))
+    return buf.value.decode()

@@ -1,0 +1,198 @@
+/*
+ * nori_hip.h — C ABI of libnori_hip.so: the MI355X (gfx950) implementation of Nori's path_mis hot path.
+ *
+ * This is the drop-in boundary (SURVEY §8 b).  The host side (Nori's plugin surface: XML parser, object
+ * factory, OBJ loader, BVH build, Integrator plugin) lives above it and hands over a flattened scene made of
+ * plain arrays; everything per-ray happens below it in hand-written HIP kernels.  No C++ types, exceptions or
+ * torch types cross this interface.  All functions return 0 on success, a negative NORI_HIP_E* code on failure
+ * (nori_hip_last_error() then holds a description for the calling thread).  A context is bound to one GPU and is
+ * thread-compatible (one caller at a time); several contexts may coexist, one per device.
+ *
+ * "Replaces" lines cite the reference interface (paths relative to the reference tree) each entry stands in for.
+ */
+#ifndef NORI_HIP_H
+#define NORI_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NORI_HIP_OK            0
+#define NORI_HIP_EINVAL       -1   /* bad argument / inconsistent scene tables */
+#define NORI_HIP_EDEVICE      -2   /* HIP runtime error (no device, allocation or launch failure) */
+#define NORI_HIP_ESTATE       -3   /* call made in the wrong state (e.g. render before upload) */
+
+#define NORI_HIP_LEAF_BIT   0x80000000u   /* child reference: bit 31 set = leaf, low 31 bits = first record */
+#define NORI_HIP_NO_CHILD   0xffffffffu   /* child reference: absent (only in the dummy root of a 1-leaf tree) */
+#define NORI_HIP_MISS       0xffffffffu   /* NoriHipHit.prim for a ray that hit nothing */
+
+/* BSDF / shape kinds (src/diffuse.cpp, src/microfacet.cpp, src/dielectric.cpp, src/mirror.cpp; src/mesh.cpp, src/sphere.cpp) */
+enum { NORI_HIP_BSDF_DIFFUSE = 0, NORI_HIP_BSDF_MICROFACET = 1, NORI_HIP_BSDF_DIELECTRIC = 2, NORI_HIP_BSDF_MIRROR = 3 };
+enum { NORI_HIP_SHAPE_MESH = 0, NORI_HIP_SHAPE_SPHERE = 1 };
+
+/*
+ * 64-byte BVH node: one inner node of the reference tree with BOTH children's boxes, so one aligned 64-B fetch
+ * decides both descents.  Replaces BVH::BVHNode (include/nori/bvh.h:127-164, 32 B, one box per node).  Node i's
+ * children are the reference's left (idx+1) and right (rightChild) nodes; boxes are bit-identical to theirs.
+ * Inner nodes are numbered in the reference's pre-order, node 0 is the root.
+ */
+typedef struct NoriHipNode {
+    float    lmin[3], lmax[3];     /* left child's box  */
+    float    rmin[3], rmax[3];     /* right child's box */
+    uint32_t left, right;          /* child references (inner index | NORI_HIP_LEAF_BIT+first record | NORI_HIP_NO_CHILD) */
+    uint32_t lcount, rcount;       /* leaf sizes (0 for inner children); informational, kernels use the record flags */
+} NoriHipNode;
+
+/*
+ * 48-byte primitive record, stored in the order of the reference's m_indices array (BVH leaf order), so the
+ * primitives of a leaf are contiguous.  Replaces the m_indices -> findShape -> m_F -> m_V gather chain of
+ * BVH::rayIntersect / Mesh::rayIntersect (src/bvh.cpp:435-449, src/mesh.cpp:84-89).
+ *   triangle: a = p0, e1 = p1 - p0, e2 = p2 - p0 (fp32 differences, as the reference computes per test)
+ *   sphere  : a = centre, e1[0] = radius
+ */
+typedef struct NoriHipPrim {
+    float    a[3];
+    float    e1[3];
+    float    e2[3];
+    uint32_t prim;                 /* global primitive id = the value in the reference's m_indices */
+    uint32_t shape_flags;          /* bits 0..23 shape index, bit 30 = sphere, bit 31 = last record of its leaf */
+    uint32_t pad;
+} NoriHipPrim;
+
+/* 96-byte per-primitive shading data, same order as NoriHipPrim.  Replaces Mesh::setHitInformation's gathers
+ * (src/mesh.cpp:123-168).  Normals / uvs are ignored unless the owning shape has them. */
+typedef struct NoriHipShadePrim {
+    float p0[3], p1[3], p2[3];
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+} NoriHipShadePrim;
+
+typedef struct NoriHipShape {
+    int32_t  type;                 /* NORI_HIP_SHAPE_* */
+    int32_t  bsdf;                 /* NORI_HIP_BSDF_* */
+    int32_t  emitter;              /* index into emitters, -1 if none */
+    uint32_t flags;                /* bit0 has vertex normals, bit1 has uvs */
+    float    albedo[3];            /* diffuse albedo | microfacet kd */
+    float    alpha, int_ior, ext_ior, ks;
+    float    center[3], radius;    /* sphere */
+    uint32_t pad;
+} NoriHipShape;
+
+/* Area emitter bound to a shape (src/arealight.cpp).  Mesh emitters sample a triangle through the normalised
+ * area CDF (include/nori/dpdf.h) stored at cdf[cdf_offset .. cdf_offset + n_tris], and read its vertices from
+ * light_prims[light_prim_offset + triangle] (mesh order, not BVH order). */
+typedef struct NoriHipEmitter {
+    float    radiance[3];
+    int32_t  shape;
+    uint32_t cdf_offset, n_tris, light_prim_offset;
+    float    area_pdf;             /* DiscretePDF::getNormalization() = 1 / total area */
+} NoriHipEmitter;
+
+typedef struct NoriHipCamera {
+    float    sample_to_camera[16]; /* row-major 4x4 (src/perspective.cpp:78-80) */
+    float    camera_to_world[16];  /* row-major 4x4 */
+    int32_t  width, height;
+    float    near_clip, far_clip;
+    float    filter_radius;        /* reconstruction filter radius: film border = ceil(radius - 0.5) (src/block.cpp:57) */
+} NoriHipCamera;
+
+typedef struct NoriHipSceneDesc {
+    uint32_t                n_nodes;   const NoriHipNode      *nodes;
+    uint32_t                n_prims;   const NoriHipPrim      *prims;
+                                       const NoriHipShadePrim *shade_prims;   /* n_prims */
+    uint32_t                root;      /* child reference of the root (inner 0, or a leaf when the tree is one leaf) */
+    float                   root_min[3], root_max[3];                          /* root box (src/bvh.cpp:342) */
+    uint32_t                n_shapes;  const NoriHipShape     *shapes;
+    uint32_t                n_emitters; const NoriHipEmitter  *emitters;
+    uint32_t                n_cdf;     const float            *cdf;
+    uint32_t                n_light_prims; const NoriHipShadePrim *light_prims;
+    NoriHipCamera           camera;
+} NoriHipSceneDesc;
+
+/* ray in, 32 B: replaces Ray3f (include/nori/ray.h:38-100); dRcp is recomputed on the device */
+typedef struct NoriHipRay { float o[3], mint, d[3], maxt; } NoriHipRay;
+/* hit out, 16 B: global primitive id (NORI_HIP_MISS if none), t, and the uv that Intersection::uv holds after
+ * setHitInformation (barycentrics, or interpolated texture coordinates when the mesh has them) */
+typedef struct NoriHipHit { uint32_t prim; float t, u, v; } NoriHipHit;
+
+typedef struct NoriHipStats {
+    uint64_t camera_samples;       /* samples started */
+    uint64_t closest_rays;         /* extend stage */
+    uint64_t shadow_rays;          /* shadow stage */
+    uint64_t invalid_samples;      /* dropped by the Color3f::isValid rule (src/block.cpp:94-98) */
+    uint64_t boxes_tested;         /* slab tests performed (two per 64-byte node fetched, plus the root box) */
+    uint64_t prims_tested;         /* ray/primitive tests performed */
+    uint64_t iterations;           /* wavefront iterations of the last render call */
+    double   render_ms;            /* device time of the last render call (HIP events on the context stream) */
+    double   extend_ms, shade_ms, shadow_ms;   /* per-stage device time of the last render call (0 if not collected) */
+} NoriHipStats;
+
+typedef struct NoriHipContext NoriHipContext;
+
+const char *nori_hip_last_error(void);
+
+/* One context per GPU.  Replaces the implicit process-wide state of the reference's renderer
+ * (cudaSetDevice(0) in cuda/CudaRender.cpp:17; Scene ownership in src/render.cpp:112-123). */
+int nori_hip_create(int device, NoriHipContext **out);
+int nori_hip_destroy(NoriHipContext *ctx);
+
+/* Copies the flattened scene to the device and (re)allocates the film.  Replaces the per-object cudaMalloc /
+ * cudaMemcpy marshalling of cuda/CudaRender.cpp:80-98 and ImageBlock::init (src/block.cpp:38-74). */
+int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *desc);
+
+/* Closest-hit (any_hit = 0) or any-hit (any_hit != 0: hits[i].prim is 1 when occluded, NORI_HIP_MISS otherwise)
+ * queries for n host rays.  Replaces Scene::rayIntersect -> BVH::rayIntersect (src/bvh.cpp:404-463) including
+ * Shape::setHitInformation's uv (src/mesh.cpp:137-141).  `full`, if not NULL, receives 16 floats per ray:
+ * p.xyz, uv.xy, shading normal xyz, geometric normal xyz, shape index, 4 x 0 (Intersection, include/nori/shape.h:38-67). */
+int nori_hip_trace(NoriHipContext *ctx, const NoriHipRay *rays, size_t n, int any_hit, NoriHipHit *hits, float *full);
+
+/* Same query on rays already resident in device memory (device pointers); asynchronous on the context's stream. */
+int nori_hip_trace_device(NoriHipContext *ctx, const NoriHipRay *d_rays, size_t n, int any_hit, NoriHipHit *d_hits);
+
+/* Primary rays for n pixel-sample positions.  Replaces PerspectiveCamera::sampleRay (src/perspective.cpp:90-111). */
+int nori_hip_camera_rays(NoriHipContext *ctx, const float *pixel_samples_xy, size_t n, NoriHipRay *rays);
+
+/* Radiance of n individual camera samples: sample i seeds pcg32 with (states[i], seqs[i]), draws the pixel jitter
+ * and the aperture sample for pixel (px[i], py[i]) as renderBlock does (src/render.cpp:85-86) — or, when `rays`
+ * is not NULL, uses rays[i] instead of the camera after consuming the same four draws; or, when px, py and rays
+ * are all NULL, places the sample anywhere on the image, pixelSample = next2D() * (width, height), as the t-test
+ * harness does (src/ttest.cpp:171-173) — and runs PathMisIntegrator::Li (src/pathMisIntegrator.cpp:18-168).
+ * Writes 3 floats per sample. */
+int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const int32_t *py, const uint64_t *states,
+                        const uint64_t *seqs, const NoriHipRay *rays, float *rgb);
+
+/* Renders samples [spp_begin, spp_end) of every pixel of the tile [x0,x1) x [y0,y1) and ACCUMULATES them into
+ * the film.  Sample s of pixel (x, y) uses the stream pcg32.seed(initstate = y*width + x, initseq = s).
+ * Replaces the body of RenderThread::renderScene's pass loop: renderBlock + ImageBlock::put
+ * (src/render.cpp:151-190, src/block.cpp:93-111). */
+int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp_begin, int spp_end);
+
+int nori_hip_clear_film(NoriHipContext *ctx);
+/* film = (height + 2*border) x (width + 2*border) float4 (r, g, b, weight) sums, row-major: ImageBlock's own
+ * layout (include/nori/block.h:48).  nori_hip_film_dims reports rows, cols, border. */
+int nori_hip_film_dims(NoriHipContext *ctx, int *rows, int *cols, int *border);
+int nori_hip_read_film(NoriHipContext *ctx, float *film_rgba);
+int nori_hip_write_film(NoriHipContext *ctx, const float *film_rgba);
+/* device pointer of the film, for in-place collectives (RCCL reduce over xGMI) by the caller */
+int nori_hip_film_device_ptr(NoriHipContext *ctx, void **d_film, size_t *bytes);
+/* height x width x 3 floats, rgb / weight.  Replaces ImageBlock::toBitmap (src/block.cpp:76-82). */
+int nori_hip_read_bitmap(NoriHipContext *ctx, float *rgb);
+
+/* NL-means filter pass over the current bitmap, on sRGB-encoded colours as the CUDA fork does
+ * (cuda/filter.cc.cu:53-110, window r, patch f, sigma, h; scene parameters cuda/nori/scene.cpp:28-32).
+ * Output: height x width x 3 floats, sRGB-encoded (what the fork stores in `image`). */
+int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, float *rgb_srgb_out);
+
+int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out);
+int nori_hip_reset_stats(NoriHipContext *ctx);
+/* stream the context launches on (hipStream_t as void*), for callers that time or order work around it */
+int nori_hip_stream(NoriHipContext *ctx, void **stream);
+int nori_hip_synchronize(NoriHipContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NORI_HIP_H */

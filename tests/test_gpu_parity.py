@@ -1,0 +1,162 @@
+"""GPU: the HIP path through the C ABI against the oracle and the reference-generated fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import nori_hip as NH
+import oracle_lib as O
+from conftest import GOLDEN, SCENES
+
+pytestmark = pytest.mark.gpu
+
+SCENE_XML = {
+    "cbox": "cbox/cbox_path_mis.xml",
+    "cbox_mirror_microfacet": "cbox/cbox_mirror_microfacet.xml",
+    "table": "table/table_path_mis.xml",
+    "table_microfacet": "table/table_path_mis_microfacet.xml",
+}
+
+
+def hits_as_u32(h):
+    return np.frombuffer(h.tobytes(), np.uint32).reshape(-1, 4)
+
+
+@pytest.fixture(scope="module")
+def loaded():
+    cache = {}
+
+    def get(name, W, H):
+        key = (name, W, H)
+        if key not in cache:
+            hs = NH.HostScene(os.path.join(SCENES, SCENE_XML[name]), W, H, 1)
+            cache[key] = (hs, hs.preprocess())
+        return cache[key]
+    yield get
+    for hs, _ in cache.values():
+        hs.close()
+
+
+@pytest.mark.parametrize("name", list(SCENE_XML))
+def test_hits_bit_exact_against_reference_fixtures(name, loaded):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    hs, ctx = loaded(name, int(g["width"]), int(g["height"]))
+    hits, full = ctx.trace(g["rays"], full=True)
+    assert np.array_equal(hits_as_u32(hits), g["hits"])                       # primary hits: prim id, t, uv bit-exact
+    assert np.array_equal(full[:, 0:5], g["full"][:, 0:5])                    # p, uv
+    assert np.array_equal(full[:, 5:12], g["full"][:, 5:12])                  # normals, shape
+    bh = ctx.trace(g["bounce_rays"])
+    assert np.array_equal(hits_as_u32(bh), g["bounce_hits"])
+    sh = ctx.trace(g["shadow_rays"], any_hit=True)
+    assert np.array_equal(sh["prim"], g["shadow_hits"])
+
+
+@pytest.mark.parametrize("name", list(SCENE_XML))
+def test_camera_rays_bit_exact_against_oracle(name, loaded):
+    hs, ctx = loaded(name, 64, 48)
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML[name]), 64, 48, 1)
+    rng = np.random.default_rng(5)
+    ps = (rng.random((4096, 2)) * [64, 48]).astype(np.float32)
+    assert np.array_equal(ctx.camera_rays(ps), o.camera_rays(ps))
+
+
+@pytest.mark.parametrize("name", list(SCENE_XML))
+def test_li_per_sample_against_reference_fixtures(name, loaded):
+    """Same pcg32 stream, same draw order: most samples follow the reference's path exactly and differ only by the
+    ulps of device sin/cos/log/exp; the few that branch differently are bounded statistically (mean)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    hs, ctx = loaded(name, int(g["width"]), int(g["height"]))
+    sel = g["li_index"]
+    li = ctx.li_samples(sel.astype(np.uint64), np.zeros(len(sel), np.uint64), rays=g["rays"][sel])
+    ref = g["li"]
+    err = np.abs(li - ref).max(1) / np.maximum(np.abs(ref).max(1), 1e-3)
+    assert (err < 1e-3).mean() > 0.97, (err < 1e-3).mean()
+    assert np.abs(li.mean(0) - ref.mean(0)).max() < 0.02 * ref.mean()
+
+
+def test_li_on_reference_test_scenes_and_their_ttests(loaded):
+    g = np.load(os.path.join(GOLDEN, "test_scenes.npz"))
+    for fname in ("test-direct.xml", "test-furnace.xml"):
+        ht = NH.HostScene(os.path.join(SCENES, "tests", fname))
+        for i in range(ht.scene_count):
+            if not ht.test_meta(i)["path_mis"]:
+                continue
+            ctx = ht.preprocess(i)
+            key = "%s_%d" % (fname.replace(".xml", "").replace("-", "_"), i)
+            rays = g[key + "_rays"]
+            n = len(rays)
+            assert np.array_equal(hits_as_u32(ctx.trace(rays)), g[key + "_hits"])
+            li = ctx.li_samples(np.arange(n, dtype=np.uint64), np.zeros(n, np.uint64), rays=rays)
+            ref = g[key + "_li"]
+            err = np.abs(li - ref).max(1) / np.maximum(np.abs(ref).max(1), 1e-3)
+            assert (err < 1e-3).mean() > 0.97, (key, (err < 1e-3).mean())
+            # the reference's own acceptance test (src/ttest.cpp, 100000 paths, Sidak-corrected alpha), on the GPU
+            r = ht.test_run(i)
+            assert r["passed"] == 1.0, (key, r)
+        ht.close()
+
+
+def test_render_matches_oracle_image_at_matched_spp(loaded):
+    """Per-sample streams are identical on both sides, so the two images are the same Monte-Carlo estimate up to
+    device-libm ulps: compared per pixel, not only statistically."""
+    W, H, spp = 96, 96, 16
+    hs, ctx = loaded("cbox", W, H)
+    ctx.clear_film(); ctx.reset_stats()
+    ctx.render(0, spp)
+    img = ctx.read_bitmap()
+    film = ctx.read_film()
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML["cbox"]), W, H, spp)
+    _, ost = o.render(0, spp, mode=1, threads=8)
+    oimg, ofilm = o.bitmap(), o.film()
+    assert np.array_equal(film[:, :, 3], ofilm[:, :, 3])                      # sample placement (weights) exact
+    rel = np.abs(img.mean((0, 1)) - oimg.mean((0, 1))) / oimg.mean((0, 1))
+    assert rel.max() < 1e-3, rel                                              # north_star: mean relative error <= 1e-3
+    close = np.abs(img - oimg).max(2) <= 1e-3 + 1e-2 * oimg.max(2)
+    assert close.mean() > 0.95, close.mean()
+    st = ctx.stats()
+    assert st["camera_samples"] == W * H * spp
+    assert abs(st["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"]
+    assert abs(st["shadow_rays"] - ost["shadow"]) < 0.01 * ost["shadow"]
+
+
+def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
+    W, H = 64, 64
+    hs, ctx = loaded("cbox", W, H)
+    ctx.clear_film(); ctx.render(0, 8)
+    whole = ctx.read_film()
+    ctx.clear_film()
+    ctx.render(0, 3); ctx.render(3, 8, tile=(0, 0, 40, H)); ctx.render(3, 8, tile=(40, 0, W, H))
+    parts = ctx.read_film()
+    assert np.array_equal(parts[:, :, 3], whole[:, :, 3])
+    assert np.allclose(parts, whole, rtol=1e-4, atol=1e-5)                    # fp32 atomics: order differs, values do not
+
+
+def test_filter_pass_matches_oracle(loaded):
+    W, H = 48, 40
+    hs, ctx = loaded("cbox", W, H)
+    ctx.clear_film(); ctx.render(0, 4)
+    img = ctx.read_bitmap()
+    out = ctx.filter(r=3, f=4, sigma=0.5, h=0.45)
+    srgb = np.where(img <= 0.0031308, 12.92 * img, 1.055 * np.power(np.maximum(img, 1e-12), 1 / 2.4) - 0.055).astype(np.float32)
+    ref = O.nl_means(srgb, 3, 4, 0.5, 0.45)
+    assert np.allclose(out, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_error_behaviour(loaded):
+    hs, ctx = loaded("cbox", 64, 64)
+    with pytest.raises(NH.NoriHipError, match="tile outside"):
+        ctx.render(0, 1, tile=(0, 0, 65, 64))
+    with pytest.raises(NH.NoriHipError, match="empty sample range"):
+        ctx.render(3, 3)
+    c2 = NH.Context()
+    with pytest.raises(NH.NoriHipError, match="no scene"):
+        c2.render(0, 1, tile=(0, 0, 1, 1))
+    # a scene table with a dangling child reference is rejected on the host, not faulted on the GPU
+    T = hs.tables()
+    nodes = T["nodes"].copy(); nodes["left"][0] = len(nodes) + 5
+    import copy, ctypes as C
+    d = NH.SceneDesc.from_buffer_copy(bytes(T["desc"]))
+    d.nodes = nodes.ctypes.data
+    with pytest.raises(NH.NoriHipError, match="child reference out of range"):
+        c2.upload(C.pointer(d))
+    c2.close()

@@ -1,0 +1,133 @@
+"""CPU: the host plugin surface (libnori_host.so) — loader, BVH build and flattening — against the oracle, plus the
+C ABI's exported symbols.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nori_hip as NH
+import oracle_lib as O
+from conftest import ROOT, SCENES
+
+XMLS = ["cbox/cbox_path_mis.xml", "cbox/cbox_mirror_microfacet.xml", "table/table_path_mis.xml", "table/table_path_mis_microfacet.xml"]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nori_hip.h")).read()
+    names = set(re.findall(r"\b(nori_hip_\w+)\s*\(", hdr))
+    assert len(names) >= 20
+    L = NH.hip_lib()
+    for n in names:
+        assert hasattr(L, n), n
+    hdr = open(os.path.join(ROOT, "include", "nori_host.h")).read()
+    L = NH.host_lib()
+    for n in set(re.findall(r"\b(nori_host_\w+)\s*\(", hdr)):
+        assert hasattr(L, n), n
+
+
+@pytest.mark.parametrize("xml", XMLS)
+def test_host_loader_and_bvh_equal_the_oracle(xml):
+    path = os.path.join(SCENES, xml)
+    hs = NH.HostScene(path, 96, 64, 2)
+    o = O.OracleScene(path, 96, 64, 2)
+    hi, oi = hs.info(), o.info()
+    assert (hi["shapes"], hi["prims"], hi["emitters"], hi["width"], hi["height"], hi["nodes"]) == (oi["shapes"], oi["prims"], oi["emitters"], 96, 64, oi["nodes"])
+    n32, idx = hs.bvh32()
+    on, oidx = o.bvh()
+    assert np.array_equal(np.frombuffer(n32.tobytes(), np.uint32).reshape(-1, 8), on)      # nodes bit-exact (flags, children, boxes)
+    assert np.array_equal(idx, oidx)                                                       # leaf order bit-exact
+    for s in range(hi["shapes"]):
+        a, b = hs.mesh(s), o.shape(s)
+        for k in ("V", "F", "cdf"):
+            assert np.array_equal(a[k], b[k])
+        for k in ("N", "UV"):
+            assert (a[k] is None) == (b[k] is None) and (a[k] is None or np.array_equal(a[k], b[k]))
+    d = hs.tables()["desc"]
+    s2c, c2w, _ = o.camera()
+    assert np.array_equal(np.array(d.camera.sample_to_camera[:], np.float32).reshape(4, 4), s2c)
+    assert np.array_equal(np.array(d.camera.camera_to_world[:], np.float32).reshape(4, 4), c2w)
+
+
+def test_flattened_tables_are_consistent():
+    hs = NH.HostScene(os.path.join(SCENES, XMLS[2]))
+    T = hs.tables()
+    n32, idx = hs.bvh32()
+    nodes, prims, shade = T["nodes"], T["prims"], T["shade"]
+    assert np.array_equal(prims["prim"], idx)                       # records are in m_indices order
+    leaves = n32[(n32["w0"] & 1) == 1]
+    inner = n32[(n32["w0"] & 1) == 0]
+    assert len(nodes) == len(inner) == len(leaves) - 1
+    last = (prims["shape_flags"] >> 31).astype(bool)
+    assert last.sum() == len(leaves)
+    ends = leaves["w1"] + (leaves["w0"] >> 1) - 1
+    assert np.array_equal(np.sort(np.nonzero(last)[0]), np.sort(ends))
+    # every child reference is in range, every leaf reference starts a leaf
+    starts = set(int(x) for x in leaves["w1"])
+    for side in ("left", "right"):
+        r = nodes[side]
+        isleaf = (r & 0x80000000) != 0
+        assert np.all(r[~isleaf] < len(nodes))
+        assert all(int(x & 0x7FFFFFFF) in starts for x in r[isleaf])
+    # child boxes are the reference nodes' boxes: node k's left child is reference node (index of inner k) + 1
+    inner_idx = np.nonzero((n32["w0"] & 1) == 0)[0]
+    assert np.array_equal(nodes["lmin"], n32["bmin"][inner_idx + 1]) and np.array_equal(nodes["lmax"], n32["bmax"][inner_idx + 1])
+    assert np.array_equal(nodes["rmin"], n32["bmin"][inner["w1"]]) and np.array_equal(nodes["rmax"], n32["bmax"][inner["w1"]])
+    assert np.array_equal(prims["a"], shade["p0"]) and np.array_equal(prims["e1"], shade["p1"] - shade["p0"])
+
+
+def test_single_leaf_scene_and_test_files_load():
+    ht = NH.HostScene(os.path.join(SCENES, "tests", "test-direct.xml"))
+    assert ht.is_test and ht.scene_count == 10
+    assert not ht.test_meta(0)["path_mis"] and ht.test_meta(5)["path_mis"]
+    assert abs(ht.test_meta(5)["reference"] - 0.0898394) < 1e-7
+    T = ht.tables(5)
+    assert T["desc"].root == 0x80000000 and len(T["nodes"]) == 0 and len(T["prims"]) == 3
+    ot = O.OracleScene(os.path.join(SCENES, "tests", "test-direct.xml"), is_test=True)
+    for i in range(10):
+        n32, idx = ht.bvh32(i)
+        on, oi = ot.bvh(i)
+        assert np.array_equal(np.frombuffer(n32.tobytes(), np.uint32).reshape(-1, 8), on) and np.array_equal(idx, oi)
+
+
+def test_parser_errors_carry_file_context():
+    import tempfile
+    bad = tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False)
+    bad.write("<scene>\n  <integrator type=\"path_mis\"/>\n  <bogus/>\n</scene>\n")
+    bad.close()
+    with pytest.raises(NH.NoriHipError, match=r'unexpected tag "bogus".*row 3'):
+        NH.HostScene(bad.name)
+    bad = tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False)
+    bad.write("<scene>\n  <integrator type=\"path_mis\"/>\n</scene>\n")
+    bad.close()
+    with pytest.raises(NH.NoriHipError, match="No camera was specified"):
+        NH.HostScene(bad.name)
+    bad = tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False)
+    bad.write("<scene><integrator type=\"nope\"/></scene>")
+    bad.close()
+    with pytest.raises(NH.NoriHipError, match='constructor for class "nope"'):
+        NH.HostScene(bad.name)
+
+
+def test_procedural_scene_builder_and_parallel_bvh_build_is_deterministic():
+    rng = np.random.default_rng(3)
+    n = 300
+    xs, ys = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+    V = np.stack([xs.ravel(), rng.random(n * n) * 0.1, ys.ravel()], 1).astype(np.float32)
+    i = np.arange(n * n).reshape(n, n)
+    a, b, c, d = i[:-1, :-1].ravel(), i[:-1, 1:].ravel(), i[1:, 1:].ravel(), i[1:, :-1].ravel()
+    F = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)]).astype(np.uint32)
+    Lv = np.array([[-0.3, 1.5, -0.3], [0.3, 1.5, -0.3], [0.3, 1.5, 0.3], [-0.3, 1.5, 0.3]], np.float32)
+    Lf = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    res = []
+    for _ in range(2):
+        sb = NH.SceneBuilder()
+        sb.add_mesh("field", V, F, color=(0.5, 0.5, 0.5))
+        sb.add_mesh("light", Lv, Lf, radiance=(10, 10, 10))
+        sb.set_camera((0, 1, 3), (0, 0, 0), (0, 1, 0), 40.0, 64, 64)
+        hs = sb.finish(spp=2)
+        n32, idx = hs.bvh32()
+        res.append((n32.copy(), idx.copy()))
+        assert hs.info()["prims"] == len(F) + 2
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
