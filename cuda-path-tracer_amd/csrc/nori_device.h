@@ -20,6 +20,10 @@ namespace nd {
 #define ND_INV_PI 0.31830988618379067154f
 #define ND_EPS 1e-4f
 
+// Correctly rounded fp32 square root.  On ROCm 7.2 sqrtf() lowers to v_sqrt_f32 plus the one-ulp correction step
+// (IEEE result), whereas __fsqrt_rn() lowers to the bare v_sqrt_f32 approximation: verified with scratch/fp_probe.hip.
+__device__ __forceinline__ float nd_sqrt(float x) { return sqrtf(x); }
+
 struct F3 { float x, y, z; };
 struct F2 { float x, y; };
 
@@ -36,10 +40,10 @@ __device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y *
 __device__ __forceinline__ F3 operator/(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
 // Eigen's unrolled 3-term reduction: x0 + (x1 + x2)
 __device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
-__device__ __forceinline__ float norm(F3 a) { return __fsqrt_rn(dot(a, a)); }
+__device__ __forceinline__ float norm(F3 a) { return nd_sqrt(dot(a, a)); }
 __device__ __forceinline__ F3 normalized(F3 a) { float n = norm(a); return a / n; }
 // reductions over dynamic-size Eigen expressions are sequential (src/mesh.cpp:69-73,154-157)
-__device__ __forceinline__ F3 normalized_seq(F3 a) { float n = __fsqrt_rn((a.x * a.x + a.y * a.y) + a.z * a.z); return a / n; }
+__device__ __forceinline__ F3 normalized_seq(F3 a) { float n = nd_sqrt((a.x * a.x + a.y * a.y) + a.z * a.z); return a / n; }
 __device__ __forceinline__ F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ bool is_zero(F3 a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
 __device__ __forceinline__ bool color_valid(F3 c) {      // Color3f::isValid, src/common.cpp:224-231
@@ -51,8 +55,8 @@ struct Frame {
     F3 s, t, n;
     __device__ __forceinline__ void set(F3 a) {
         n = a; F3 c;
-        if (fabsf(a.x) > fabsf(a.y)) { float invLen = 1.0f / __fsqrt_rn(a.x * a.x + a.z * a.z); c = f3(a.z * invLen, 0.0f, -a.x * invLen); }
-        else { float invLen = 1.0f / __fsqrt_rn(a.y * a.y + a.z * a.z); c = f3(0.0f, a.z * invLen, -a.y * invLen); }
+        if (fabsf(a.x) > fabsf(a.y)) { float invLen = 1.0f / nd_sqrt(a.x * a.x + a.z * a.z); c = f3(a.z * invLen, 0.0f, -a.x * invLen); }
+        else { float invLen = 1.0f / nd_sqrt(a.y * a.y + a.z * a.z); c = f3(0.0f, a.z * invLen, -a.y * invLen); }
         t = c; s = cross(c, a);
     }
     __device__ __forceinline__ F3 toLocal(F3 v) const { return f3(dot(v, s), dot(v, t), dot(v, n)); }
@@ -178,7 +182,7 @@ __device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit
                     float Cq = ((-rad * rad + dot(c, c)) + dot(o, o)) - 2 * dot(c, o);
                     float discr = Bq * Bq - 4 * Cq;
                     if (discr > 0) {
-                        float sq = __fsqrt_rn(discr);
+                        float sq = nd_sqrt(discr);
                         float t1 = (-Bq + sq) * 0.5f, t2 = (-Bq - sq) * 0.5f;
                         bool v1 = t1 >= mint && t1 <= maxt, v2 = t2 >= mint && t2 <= maxt;
                         if (v1 && v2) { t = (t2 < t1) ? t2 : t1; h = true; }
@@ -289,21 +293,21 @@ __device__ __forceinline__ void camera_ray(const DevScene &sc, F2 ps, Ray &ray) 
 
 // ---- warps (src/warp.cpp:59-63,221-244,263-267) ----------------------------------------------------------
 __device__ __forceinline__ F3 square_to_cosine_hemisphere(F2 s) {
-    float r = __fsqrt_rn(s.x);
+    float r = nd_sqrt(s.x);
     float theta = 2 * ND_PI * s.y;
     float sn, cs; sincosf(theta, &sn, &cs);
     float dx = r * cs, dy = r * sn;
-    return f3(dx, dy, __fsqrt_rn(1.0f - dx * dx - dy * dy));
+    return f3(dx, dy, nd_sqrt(1.0f - dx * dx - dy * dy));
 }
 __device__ __forceinline__ F3 square_to_beckmann(F2 s, float alpha) {
     float inner = 1.0f / (1.0f - alpha * alpha * logf(1.0f - s.x));
-    float theta = acosf(__fsqrt_rn(inner));
+    float theta = acosf(nd_sqrt(inner));
     float phi = s.y * 2.0f * ND_PI;
     float st, ct, sp, cp; sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
     return f3(st * cp, st * sp, ct);
 }
 __device__ __forceinline__ F3 square_to_uniform_triangle(F2 s) {
-    float su1 = __fsqrt_rn(s.x);
+    float su1 = nd_sqrt(s.x);
     float u = 1.f - su1, v = s.y * su1;
     return f3(u, v, 1.f - u - v);
 }
@@ -315,12 +319,12 @@ __device__ __forceinline__ float fresnel(float cosThetaI, float extIOR, float in
     if (cosThetaI < 0.0f) { float s = etaI; etaI = etaT; etaT = s; cosThetaI = -cosThetaI; }
     float eta = etaI / etaT, sinThetaTSqr = eta * eta * (1 - cosThetaI * cosThetaI);
     if (sinThetaTSqr > 1.0f) return 1.0f;
-    float cosThetaT = __fsqrt_rn(1.0f - sinThetaTSqr);
+    float cosThetaT = nd_sqrt(1.0f - sinThetaTSqr);
     float Rs = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
     float Rp = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
     return (Rs * Rs + Rp * Rp) / 2.0f;
 }
-__device__ __forceinline__ float tan_theta(F3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return __fsqrt_rn(temp) / v.z; }
+__device__ __forceinline__ float tan_theta(F3 v) { float temp = 1 - v.z * v.z; if (temp <= 0.0f) return 0.0f; return nd_sqrt(temp) / v.z; }
 
 // ---- BSDFs ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float beckmann_D(float alpha, F3 m) {          // src/microfacet.cpp:55-61
@@ -433,7 +437,7 @@ __device__ __forceinline__ F3 emitter_sample(const DevScene &sc, const NoriHipEm
     F3 p, n; float apdf;
     if (shp.type == NORI_HIP_SHAPE_SPHERE) {                              // src/sphere.cpp:143-149, src/warp.cpp:26-31,198-203
         float phi = 2 * ND_PI * sample.x, sn, cs; sincosf(phi, &sn, &cs);
-        float z = 2.0f * sample.y - 1.0f; float r = __fsqrt_rn(1.0f - (z * z));
+        float z = 2.0f * sample.y - 1.0f; float r = nd_sqrt(1.0f - (z * z));
         F3 q = f3(cs * r, sn * r, z);
         p = f3(shp.center) + shp.radius * q; n = q;
         apdf = (float) (1.0 / (4.0 * ND_PI * shp.radius * shp.radius));
