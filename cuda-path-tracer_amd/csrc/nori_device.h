@@ -129,100 +129,118 @@ __device__ __forceinline__ bool slab(const float *bmin, const float *bmax, F3 o,
 
 // BVH::rayIntersect (src/bvh.cpp:404-463) over 64-byte two-box nodes, in the reference's visiting order
 // (left subtree first, right pushed), so closest-hit ties resolve to the same primitive.
-// Stack entries are (child reference, entry distance); `stk` may live in LDS or scratch.
-template <bool ANY, typename StackT>
-__device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
-    F3 o = ray_in.o, d = ray_in.d;
-    float mint = ray_in.mint, maxt = ray_in.maxt;
-    hit.pos = 0xffffffffu; hit.t = ND_INF; hit.u = hit.v = 0.f;
-    if (mint == ND_EPS) {                       // adaptive epsilon, src/bvh.cpp:411-412
-        float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
-        float e = mint * m; mint = (mint < e) ? e : mint;
+// Stack entries are (child reference, entry distance); the stack type decides where they live (LDS / scratch).
+//
+// Trav is the traversal as a resumable state machine: begin() tests the root box, inner_step() visits one 64-byte
+// node, leaf_step() tests the records of one leaf and pops.  Persistent kernels interleave these steps with
+// fetching new rays for lanes that have finished ("while-while" traversal with dynamic fetch).
+#define ND_DONE 0x7fffffffu        /* cur value of a finished traversal (never a valid inner index, no leaf bit) */
+
+template <bool ANY> struct Trav {
+    F3 o, d, rcp; float mint, maxt; uint32_t cur; int sp; Hit hit; bool found;
+
+    template <typename StackT> __device__ __forceinline__ void pop(StackT &stk) {
+        // an entry is skipped when its box no longer passes with the current maxt
+        while (sp > 0) { uint2 e = stk.pop(--sp); if (__uint_as_float(e.y) <= maxt) { cur = e.x; return; } }
+        cur = ND_DONE;
     }
-    if (maxt < mint) return false;
-    F3 rcp = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    float nr;
-    n_nodes++;
-    if (!slab(sc.root_min, sc.root_max, o, d, rcp, mint, maxt, nr)) return false;
-    uint32_t cur = sc.root;
-    int sp = 0;
-    bool found = false;
-    for (;;) {
-        if (cur & NORI_HIP_LEAF_BIT) {
-            uint32_t pos = cur & 0x7fffffffu;
-            uint32_t flags;
-            do {
-                const float4 *r = sc.prims + 3 * (size_t) pos;
-                float4 A = r[0], B = r[1], C = r[2];
-                flags = __float_as_uint(C.z);
-                n_prims++;
-                float t = 0.f, u = 0.f, v = 0.f; bool h = false;
-                if (!(flags & 0x40000000u)) {
-                    // Mesh::rayIntersect, src/mesh.cpp:84-121
-                    F3 p0 = f3(A.x, A.y, A.z), edge1 = f3(A.w, B.x, B.y), edge2 = f3(B.z, B.w, C.x);
-                    F3 pvec = cross(d, edge2);
-                    float det = dot(edge1, pvec);
-                    if (!(det > -1e-8f && det < 1e-8f)) {
-                        float inv_det = 1.0f / det;
-                        F3 tvec = o - p0;
-                        u = dot(tvec, pvec) * inv_det;
-                        if (!(u < 0.0f || u > 1.0f)) {
-                            F3 qvec = cross(tvec, edge1);
-                            v = dot(d, qvec) * inv_det;
-                            if (!(v < 0.0f || u + v > 1.0f)) {
-                                t = dot(edge2, qvec) * inv_det;
-                                h = t >= mint && t <= maxt;
-                            }
+    // false: the ray ends without entering the tree
+    __device__ __forceinline__ bool begin(const DevScene &sc, const Ray &r, uint32_t &n_boxes) {
+        o = r.o; d = r.d; mint = r.mint; maxt = r.maxt; sp = 0; found = false; cur = ND_DONE;
+        hit.pos = 0xffffffffu; hit.t = ND_INF; hit.u = hit.v = 0.f;
+        if (mint == ND_EPS) {                       // adaptive epsilon, src/bvh.cpp:411-412
+            float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
+            float e = mint * m; mint = (mint < e) ? e : mint;
+        }
+        if (maxt < mint) return false;
+        rcp = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        float nr; n_boxes++;
+        if (!slab(sc.root_min, sc.root_max, o, d, rcp, mint, maxt, nr)) return false;
+        cur = sc.root;
+        return true;
+    }
+    template <typename StackT> __device__ __forceinline__ void inner_step(const DevScene &sc, StackT &stk, uint32_t &n_boxes) {
+        const float4 *q = reinterpret_cast<const float4 *>(sc.nodes + cur);
+        float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+        float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+        float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+        uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+        float nl, nrr = 0.f;
+        n_boxes += 2;
+        bool hl = slab(lmin, lmax, o, d, rcp, mint, maxt, nl);
+        bool hr = (right != NORI_HIP_NO_CHILD) && slab(rmin, rmax, o, d, rcp, mint, maxt, nrr);
+        if (hl) { if (hr) { stk.push(sp++, make_uint2(right, __float_as_uint(nrr))); } cur = left; }
+        else if (hr) cur = right;
+        else pop(stk);
+    }
+    template <typename StackT> __device__ __forceinline__ void leaf_step(const DevScene &sc, StackT &stk, uint32_t &n_prims) {
+        uint32_t pos = cur & 0x7fffffffu;
+        uint32_t flags;
+        do {
+            const float4 *r = sc.prims + 3 * (size_t) pos;
+            float4 A = r[0], B = r[1], C = r[2];
+            flags = __float_as_uint(C.z);
+            n_prims++;
+            float t = 0.f, u = 0.f, v = 0.f; bool h = false;
+            if (!(flags & 0x40000000u)) {
+                // Mesh::rayIntersect, src/mesh.cpp:84-121
+                F3 p0 = f3(A.x, A.y, A.z), edge1 = f3(A.w, B.x, B.y), edge2 = f3(B.z, B.w, C.x);
+                F3 pvec = cross(d, edge2);
+                float det = dot(edge1, pvec);
+                if (!(det > -1e-8f && det < 1e-8f)) {
+                    float inv_det = 1.0f / det;
+                    F3 tvec = o - p0;
+                    u = dot(tvec, pvec) * inv_det;
+                    if (!(u < 0.0f || u > 1.0f)) {
+                        F3 qvec = cross(tvec, edge1);
+                        v = dot(d, qvec) * inv_det;
+                        if (!(v < 0.0f || u + v > 1.0f)) {
+                            t = dot(edge2, qvec) * inv_det;
+                            h = t >= mint && t <= maxt;
                         }
                     }
-                } else {
-                    // Sphere::rayIntersect, src/sphere.cpp:42-113
-                    F3 c = f3(A.x, A.y, A.z); float rad = A.w;
-                    float Bq = 2 * dot(o - c, d);
-                    float Cq = ((-rad * rad + dot(c, c)) + dot(o, o)) - 2 * dot(c, o);
-                    float discr = Bq * Bq - 4 * Cq;
-                    if (discr > 0) {
-                        float sq = nd_sqrt(discr);
-                        float t1 = (-Bq + sq) * 0.5f, t2 = (-Bq - sq) * 0.5f;
-                        bool v1 = t1 >= mint && t1 <= maxt, v2 = t2 >= mint && t2 <= maxt;
-                        if (v1 && v2) { t = (t2 < t1) ? t2 : t1; h = true; }
-                        else if (v1) { t = t1; h = true; }
-                        else if (v2) { t = t2; h = true; }
-                    } else if (discr == 0) {
-                        float tt = -Bq * 0.5f;
-                        if (tt >= mint && tt < maxt) { t = tt; h = true; }
-                    }
                 }
-                if (h) {
-                    if (ANY) return true;
-                    found = true; maxt = t; hit.pos = pos; hit.t = t; hit.u = u; hit.v = v;
+            } else {
+                // Sphere::rayIntersect, src/sphere.cpp:42-113
+                F3 c = f3(A.x, A.y, A.z); float rad = A.w;
+                float Bq = 2 * dot(o - c, d);
+                float Cq = ((-rad * rad + dot(c, c)) + dot(o, o)) - 2 * dot(c, o);
+                float discr = Bq * Bq - 4 * Cq;
+                if (discr > 0) {
+                    float sq = nd_sqrt(discr);
+                    float t1 = (-Bq + sq) * 0.5f, t2 = (-Bq - sq) * 0.5f;
+                    bool v1 = t1 >= mint && t1 <= maxt, v2 = t2 >= mint && t2 <= maxt;
+                    if (v1 && v2) { t = (t2 < t1) ? t2 : t1; h = true; }
+                    else if (v1) { t = t1; h = true; }
+                    else if (v2) { t = t2; h = true; }
+                } else if (discr == 0) {
+                    float tt = -Bq * 0.5f;
+                    if (tt >= mint && tt < maxt) { t = tt; h = true; }
                 }
-                pos++;
-            } while (!(flags & 0x80000000u));
-            // pop: an entry is skipped when its box no longer passes with the current maxt
-            bool got = false;
-            while (sp > 0) { uint2 e = stk.pop(--sp); if (__uint_as_float(e.y) <= maxt) { cur = e.x; got = true; break; } }
-            if (!got) break;
-        } else {
-            const float4 *q = reinterpret_cast<const float4 *>(sc.nodes + cur);
-            float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
-            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
-            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
-            uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
-            float nl, nrr;
-            n_nodes += 2;
-            bool hl = slab(lmin, lmax, o, d, rcp, mint, maxt, nl);
-            bool hr = (right != NORI_HIP_NO_CHILD) && slab(rmin, rmax, o, d, rcp, mint, maxt, nrr);
-            if (hl) { if (hr) { stk.push(sp++, make_uint2(right, __float_as_uint(nrr))); } cur = left; }
-            else if (hr) cur = right;
-            else {
-                bool got = false;
-                while (sp > 0) { uint2 e = stk.pop(--sp); if (__uint_as_float(e.y) <= maxt) { cur = e.x; got = true; break; } }
-                if (!got) break;
             }
+            if (h) {
+                found = true;
+                if (ANY) { cur = ND_DONE; return; }
+                maxt = t; hit.pos = pos; hit.t = t; hit.u = u; hit.v = v;
+            }
+            pos++;
+        } while (!(flags & 0x80000000u));
+        pop(stk);
+    }
+};
+
+// run one ray to completion
+template <bool ANY, typename StackT>
+__device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
+    Trav<ANY> tv;
+    if (tv.begin(sc, ray_in, n_nodes)) {
+        while (tv.cur != ND_DONE) {
+            while (!(tv.cur & NORI_HIP_LEAF_BIT) && tv.cur != ND_DONE) tv.inner_step(sc, stk, n_nodes);
+            if (tv.cur != ND_DONE) tv.leaf_step(sc, stk, n_prims);
         }
     }
-    return found;
+    hit = tv.hit;
+    return tv.found;
 }
 
 // per-lane stack in private (scratch) memory
@@ -476,13 +494,16 @@ __device__ __forceinline__ void path_init(PathState &ps, const Ray &r) {
 }
 struct Counters { uint32_t closest, shadow, nodes, prims; };
 
-// One iteration of the reference's bounce loop.  Returns false when the path has ended.
-// A zero BSDF weight ends the path: the reference keeps bouncing with zero throughput, which adds exact zeros.
-template <typename StackT>
-__device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
-    Hit hit;
-    ctr.closest++;
-    if (!trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+// What the shading of one hit leaves behind for the shadow stage
+struct ShadeOut { bool end; bool has_shadow; Ray shadow; F3 contrib; };
+
+// The part of one bounce between the closest-hit query and the shadow query (src/pathMisIntegrator.cpp:42-164):
+// emission with the MIS weight of the previous BSDF sample, Russian roulette, BSDF sampling, emitter sampling.
+// Updates ps (radiance so far, throughput, next ray, last pdf); out.contrib is what the NEE adds if the shadow ray
+// is unoccluded.  out.end: the path stops after this bounce (roulette, or a zero BSDF weight — the reference keeps
+// bouncing with zero throughput, which adds exact zeros).
+__device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg32 &rng, const Hit &hit, ShadeOut &out) {
+    out.end = false; out.has_shadow = false; out.contrib = f3(0.f);
     Surface sf;
     surface_from_hit(sc, ps.ray, hit, sf, false);
     const NoriHipShape &shp = sc.shapes[sf.shape];
@@ -496,7 +517,7 @@ __device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, P
         if (wmat > 0.0f) ps.li = ps.li + (wmat * ps.t) * flight;
     }
     const float successProb = 0.95f;                                      // :67-77
-    if (rng.next1D() > successProb) return false;
+    if (rng.next1D() > successProb) { out.end = true; return; }
     ps.t = ps.t / successProb;
 
     F3 wi_l = sf.sh.toLocal(-ps.ray.d);                                   // :81-109
@@ -512,23 +533,35 @@ __device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, P
         uint32_t n = sc.n_emitters;
         uint32_t index = (uint32_t) floorf((float) n * pick); if (index > n - 1) index = n - 1;
         const NoriHipEmitter &em = sc.emitters[index];
-        F3 lwi, ln, lp; Ray shadow;
-        F3 liLoc = emitter_sample(sc, em, sf.p, rng.next2D(), lwi, ln, lp, shadow);
-        Hit sh_hit;
-        ctr.shadow++;
-        if (!trace<true>(sc, shadow, sh_hit, stk, ctr.nodes, ctr.prims)) {
-            F3 wo_l = sf.sh.toLocal(lwi);
-            float bpdf = bsdf_pdf(shp, wi_l, wo_l);
-            float lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), sf.p, lp, ln, lwi);
-            float wem = lpdf / (lpdf + bpdf);
-            float cosS = dot(normalized(lwi), normalized(sf.sh.n));
-            if (wem > 0) ps.li = ps.li + ((((ps.t * wem) * liLoc) * bsdf_eval(shp, wi_l, wo_l)) * fabsf(cosS)) * (float) n;
-        }
+        F3 lwi, ln, lp;
+        F3 liLoc = emitter_sample(sc, em, sf.p, rng.next2D(), lwi, ln, lp, out.shadow);
+        out.has_shadow = true;
+        F3 wo_l = sf.sh.toLocal(lwi);
+        float bpdf = bsdf_pdf(shp, wi_l, wo_l);
+        float lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), sf.p, lp, ln, lwi);
+        float wem = lpdf / (lpdf + bpdf);
+        float cosS = dot(normalized(lwi), normalized(sf.sh.n));
+        if (wem > 0) out.contrib = ((((ps.t * wem) * liLoc) * bsdf_eval(shp, wi_l, wo_l)) * fabsf(cosS)) * (float) n;
     }
-    if (!wo_valid || is_zero(f)) return false;
+    if (!wo_valid || is_zero(f)) { out.end = true; return; }
     ps.ray.d = next_dir; ps.ray.o = sf.p; ps.ray.mint = 1e-3f; ps.ray.maxt = ND_INF;
     ps.t = ps.t * f;
-    return true;
+}
+
+// One iteration of the reference's bounce loop, run to completion by one lane.  Returns false when the path ended.
+template <typename StackT>
+__device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
+    Hit hit;
+    ctr.closest++;
+    if (!trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+    ShadeOut so;
+    shade_hit(sc, ps, rng, hit, so);
+    if (so.has_shadow) {
+        Hit sh_hit;
+        ctr.shadow++;
+        if (!trace<true>(sc, so.shadow, sh_hit, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
+    }
+    return !so.end;
 }
 
 } // namespace nd

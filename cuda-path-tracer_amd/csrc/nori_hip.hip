@@ -16,6 +16,8 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <algorithm>
+#include <cstdlib>
 #include "nori_device.h"
 
 #pragma clang fp contract(off)
@@ -163,6 +165,170 @@ __global__ __launch_bounds__(256) void k_render(DevScene sc, RenderJob job, floa
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Wavefront pipeline: the bounce loop of PathMisIntegrator::Li cut into stages that run as separate kernels over
+// a pool of path slots (struct-of-arrays in HBM), so that each kernel keeps few registers live and every lane of
+// a wave does the same kind of work:
+//   k_shade        shades the hits of the previous extend (emission+MIS, roulette, BSDF sample, emitter sample),
+//                  splats finished paths and regenerates their slots from the global work counter, queues the
+//                  shadow rays and the slots that go on
+//   k_trace_queue  <ANY=true>  shadow stage: any-hit for the queued shadow rays, adds the NEE term when unoccluded
+//                  <ANY=false> extend stage: closest hit for every live slot
+// Both trace stages are persistent waves that pull rays from their queue through one atomic head counter and refill
+// a lane as soon as its ray has finished (while-while traversal with dynamic fetch), so lanes do not idle behind
+// the longest traversal of their wave.
+enum { PF_LAST_DELTA = 1u, PF_ENDING = 2u, PF_ACTIVE = 4u };
+
+struct Pool {
+    float4 *ray_o;     // o.xyz, mint
+    float4 *ray_d;     // d.xyz, maxt
+    uint4  *hit;       // record index (0xffffffff = miss), t, u, v
+    float4 *thr;       // throughput rgb, pdf of the last BSDF sample
+    float4 *li;        // radiance so far rgb, flags (PF_*)
+    uint4  *rng;       // pcg32 state, inc
+    float4 *pix;       // pixel sample x, y, integer pixel (x | y << 16), unused
+    float4 *sh_o;      // shadow ray o.xyz, mint
+    float4 *sh_d;      // shadow ray d.xyz, maxt
+    float4 *sh_c;      // NEE contribution rgb if unoccluded
+};
+struct WfCounters { unsigned int n_active[2]; unsigned int n_shadow; unsigned int head_extend; unsigned int head_shadow; unsigned int pad[3]; };
+
+__global__ void k_pool_init(Pool pool, unsigned int *queue, unsigned int n, WfCounters *cnt) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { queue[i] = i; pool.li[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u)); }
+    if (i == 0) { cnt->n_active[0] = n; cnt->n_active[1] = 0; cnt->n_shadow = 0; cnt->head_extend = 0; cnt->head_shadow = 0; }
+}
+__global__ void k_iter_begin(WfCounters *cnt, int cur) { cnt->n_active[1 - cur] = 0; cnt->n_shadow = 0; cnt->head_extend = 0; cnt->head_shadow = 0; }
+
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, RenderJob job, float4 *film, const unsigned int *q_in, const unsigned int *n_in_ptr,
+                                               unsigned int *q_next, unsigned int *n_next, unsigned int *q_shadow, unsigned int *n_shadow,
+                                               unsigned long long *work_counter, DevStats *stats) {
+    const unsigned int n_in = *n_in_ptr;
+    const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
+    const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
+    unsigned int n_samples = 0, n_invalid = 0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
+        const unsigned int slot = q_in[i];
+        float4 L = pool.li[slot];
+        unsigned int flags = __float_as_uint(L.w);
+        bool go_on = false;
+        if (flags & PF_ACTIVE) {
+            uint4 h = pool.hit[slot];
+            float4 P = pool.pix[slot];
+            bool ended = true;
+            PathState ps; ps.li = f3(L.x, L.y, L.z);
+            if (h.x != 0xffffffffu) {
+                float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot];
+                uint4 R = pool.rng[slot];
+                ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
+                ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
+                Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
+                Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
+                ShadeOut so;
+                shade_hit(sc, ps, rng, hit, so);
+                flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
+                if (so.has_shadow) {
+                    pool.sh_o[slot] = make_float4(so.shadow.o.x, so.shadow.o.y, so.shadow.o.z, so.shadow.mint);
+                    pool.sh_d[slot] = make_float4(so.shadow.d.x, so.shadow.d.y, so.shadow.d.z, so.shadow.maxt);
+                    pool.sh_c[slot] = make_float4(so.contrib.x, so.contrib.y, so.contrib.z, 0.f);
+                    q_shadow[atomicAdd(n_shadow, 1u)] = slot;
+                }
+                if (!so.end) {
+                    ended = false; go_on = true;
+                    pool.ray_o[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.mint);
+                    pool.ray_d[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.ray.maxt);
+                    pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
+                    pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
+                    pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
+                } else if (so.has_shadow) {
+                    // the path ends, but its last NEE term is still pending: the shadow stage adds it, splats and frees the slot
+                    ended = false; go_on = true;
+                    flags |= PF_ENDING;
+                    pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);          // maxt < mint: the extend stage skips it
+                    pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
+                }
+            }
+            if (ended) {
+                unsigned int pxy = __float_as_uint(P.z);
+                if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
+                flags = 0u;
+            }
+        }
+        if (!(flags & PF_ACTIVE)) {
+            // regenerate: next camera sample from the global counter (src/render.cpp:83-98)
+            for (;;) {
+                unsigned long long w = atomicAdd(work_counter, 1ull);
+                if (w >= padded_total) { pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u)); break; }
+                int px, py, s; work_to_sample(job, w, px, py, s);
+                if (px >= job.x0 + job.tw || py >= job.y0 + job.th) continue;
+                Pcg32 rng; rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) s);
+                F2 j = rng.next2D();
+                F2 pixel_sample = f2((float) px + j.x, (float) py + j.y);
+                (void) rng.next2D();
+                Ray r; camera_ray(sc, pixel_sample, r);
+                pool.ray_o[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.mint);
+                pool.ray_d[slot] = make_float4(r.d.x, r.d.y, r.d.z, r.maxt);
+                pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+                pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
+                pool.pix[slot] = make_float4(pixel_sample.x, pixel_sample.y, __uint_as_float((unsigned int) px | ((unsigned int) py << 16)), 0.f);
+                pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(PF_ACTIVE | PF_LAST_DELTA));
+                n_samples++; go_on = true;
+                break;
+            }
+        }
+        if (go_on) q_next[atomicAdd(n_next, 1u)] = slot;
+    }
+    unsigned long long v0 = n_samples, v1 = n_invalid;
+    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
+    if ((threadIdx.x & 63) == 0 && (v0 | v1)) { atomicAdd(&stats->samples, v0); atomicAdd(&stats->invalid, v1); }
+}
+
+template <bool ANY>
+__global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, const unsigned int *n_ptr, unsigned int *head, DevStats *stats) {
+    const unsigned int n = *n_ptr;
+    ScratchStack stk;
+    Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0;
+    bool have = false, exhausted = false; unsigned int slot = 0;
+    uint32_t n_boxes = 0, n_prims = 0, n_rays = 0;
+    for (;;) {
+        if (!have && !exhausted) {
+            unsigned int idx = atomicAdd(head, 1u);
+            if (idx < n) {
+                slot = queue[idx];
+                float4 ro = ANY ? pool.sh_o[slot] : pool.ray_o[slot], rd = ANY ? pool.sh_d[slot] : pool.ray_d[slot];
+                Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
+                if (!(r.maxt < r.mint)) n_rays++;
+                have = true;
+                if (!tv.begin(sc, r, n_boxes)) tv.cur = ND_DONE;
+            } else exhausted = true;
+        }
+        if (__ballot(have) == 0ull) { if (__ballot(!exhausted) == 0ull) break; continue; }
+        if (have) {
+            while (!(tv.cur & NORI_HIP_LEAF_BIT) && tv.cur != ND_DONE) tv.inner_step(sc, stk, n_boxes);
+            if (tv.cur != ND_DONE) tv.leaf_step(sc, stk, n_prims);
+            if (tv.cur == ND_DONE) {
+                if (ANY) {
+                    float4 L = pool.li[slot];
+                    unsigned int flags = __float_as_uint(L.w);
+                    if (!tv.found) { float4 c = pool.sh_c[slot]; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+                    if (flags & PF_ENDING) {
+                        float4 P = pool.pix[slot]; unsigned int pxy = __float_as_uint(P.z);
+                        if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), f3(L.x, L.y, L.z))) atomicAdd(&stats->invalid, 1ull);
+                        L = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+                    }
+                    pool.li[slot] = L;
+                } else {
+                    pool.hit[slot] = make_uint4(tv.hit.pos, __float_as_uint(tv.hit.t), __float_as_uint(tv.hit.u), __float_as_uint(tv.hit.v));
+                }
+                have = false;
+            }
+        }
+    }
+    unsigned long long v[3] = {n_rays, n_boxes, n_prims};
+    for (int k = 0; k < 3; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
+    if ((threadIdx.x & 63) == 0 && v[0]) { atomicAdd(ANY ? &stats->shadow : &stats->closest, v[0]); atomicAdd(&stats->nodes, v[1]); atomicAdd(&stats->prims, v[2]); }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 __global__ void k_bitmap(const float4 *film, int w, int h, int border, int cols, float *rgb) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
@@ -244,6 +410,11 @@ struct NoriHipContext {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     NoriHipStats stats;
     int n_cus = 256;
+    // wavefront pipeline
+    unsigned int pool_slots = 0; Pool pool; void *pool_mem = nullptr;
+    unsigned int *d_queue[2] = {nullptr, nullptr}, *d_qshadow = nullptr; WfCounters *d_cnt = nullptr;
+    unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
     void free_scene() {
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
@@ -274,6 +445,12 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipMalloc((void **) &c->d_stats, sizeof(DevStats)));
     HIPCHK(hipMemset(c->d_stats, 0, sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
+    if (const char *e = getenv("NORI_HIP_PIPELINE")) c->pipeline = (std::string(e) == "mega") ? 0 : 1;
+    c->pool_slots = 1u << 20;
+    if (const char *e = getenv("NORI_HIP_POOL")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) c->pool_slots = (unsigned int) v; }
+    HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
+    HIPCHK(hipHostMalloc((void **) &c->h_ring, 4 * sizeof(unsigned int), hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
     *out = c;
     return NORI_HIP_OK;
 }
@@ -283,7 +460,10 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
-    hipFree(ctx->d_counter); hipFree(ctx->d_stats);
+    hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
+    hipFree(ctx->d_queue[0]); hipFree(ctx->d_queue[1]); hipFree(ctx->d_qshadow);
+    if (ctx->h_ring) hipHostFree(ctx->h_ring);
+    for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -426,16 +606,59 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     RenderJob job; job.x0 = x0; job.y0 = y0; job.tw = x1 - x0; job.th = y1 - y0; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin;
     job.total = (unsigned long long) job.tw * job.th * job.nspp;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
-    // persistent grid: enough resident waves to cover latency, capped by the amount of work
-    unsigned long long chunks = (job.total + 255) / 256;
-    unsigned blocks = (unsigned) ctx->n_cus * 8u;
-    if ((unsigned long long) blocks > chunks) blocks = (unsigned) chunks;
-    if (blocks == 0) blocks = 1;
+    if (ctx->pipeline == 0) {
+        // single persistent kernel with per-lane path regeneration
+        unsigned long long chunks = (job.total + 255) / 256;
+        unsigned blocks = (unsigned) ctx->n_cus * 8u;
+        if ((unsigned long long) blocks > chunks) blocks = (unsigned) chunks;
+        if (blocks == 0) blocks = 1;
+        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        ctx->stats.iterations = 1;
+        return NORI_HIP_OK;
+    }
+    // ---- wavefront stages over a pool of path slots
+    if (!ctx->pool_mem) {
+        const size_t P = ctx->pool_slots;
+        HIPCHK(hipMalloc(&ctx->pool_mem, P * 10 * sizeof(float4)));
+        float4 *base = (float4 *) ctx->pool_mem;
+        Pool &pl = ctx->pool;
+        pl.ray_o = base; pl.ray_d = base + P; pl.hit = (uint4 *) (base + 2 * P); pl.thr = base + 3 * P; pl.li = base + 4 * P;
+        pl.rng = (uint4 *) (base + 5 * P); pl.pix = base + 6 * P; pl.sh_o = base + 7 * P; pl.sh_d = base + 8 * P; pl.sh_c = base + 9 * P;
+        HIPCHK(hipMalloc((void **) &ctx->d_queue[0], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_queue[1], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_qshadow, P * 4));
+    }
+    unsigned int P = ctx->pool_slots;
+    if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
+    const unsigned trace_blocks = (unsigned) ctx->n_cus * 8u;
+    const unsigned shade_blocks = std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * 16u);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_render, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats);
-    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, ctx->d_queue[0], P, ctx->d_cnt);
+    int cur = 0; uint64_t it = 0;
+    for (;; ++it) {
+        WfCounters *c = ctx->d_cnt;
+        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c, cur);
+        hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, job, ctx->d_film, (const unsigned int *) ctx->d_queue[cur],
+                           (const unsigned int *) &c->n_active[cur], ctx->d_queue[1 - cur], &c->n_active[1 - cur], ctx->d_qshadow, &c->n_shadow, ctx->d_counter, ctx->d_stats);
+        hipLaunchKernelGGL(k_trace_queue<true>, dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qshadow,
+                           (const unsigned int *) &c->n_shadow, &c->head_shadow, ctx->d_stats);
+        hipLaunchKernelGGL(k_trace_queue<false>, dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_queue[1 - cur],
+                           (const unsigned int *) &c->n_active[1 - cur], &c->head_extend, ctx->d_stats);
+        HIPCHK(hipGetLastError());
+        // the number of live slots comes back through a 4-deep ring of pinned words, so the host runs at most three
+        // iterations ahead of the device and never waits on the iteration it has just queued
+        HIPCHK(hipMemcpyAsync(&ctx->h_ring[it & 3], &c->n_active[1 - cur], sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ring_ev[it & 3], ctx->stream));
+        cur = 1 - cur;
+        if (it >= 3) {
+            HIPCHK(hipEventSynchronize(ctx->ring_ev[(it - 3) & 3]));
+            if (ctx->h_ring[(it - 3) & 3] == 0) break;
+        }
+        if (it > (1ull << 24)) return fail(NORI_HIP_EDEVICE, "wavefront loop did not terminate");
+    }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->stats.iterations = 1;
+    ctx->stats.iterations = it + 1;
     return NORI_HIP_OK;
 }
 

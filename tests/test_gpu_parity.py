@@ -131,6 +131,32 @@ def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
     assert np.allclose(parts, whole, rtol=1e-4, atol=1e-5)                    # fp32 atomics: order differs, values do not
 
 
+@pytest.mark.parametrize("name", ["cbox_mirror_microfacet", "table"])
+def test_wavefront_and_single_kernel_pipelines_agree(name):
+    """The staged pipeline (shade / shadow / extend kernels over a slot pool) and the single persistent kernel run the
+    same per-sample arithmetic; only the fp32 atomic summation order into the film differs.  A small slot pool forces
+    many regeneration rounds and a long tail."""
+    W, H, spp = 80, 56, 6
+    films, stats = [], []
+    for mode, pool in (("wavefront", "4096"), ("wavefront", "1048576"), ("mega", "4096")):
+        os.environ["NORI_HIP_PIPELINE"] = mode
+        os.environ["NORI_HIP_POOL"] = pool
+        try:
+            hs = NH.HostScene(os.path.join(SCENES, SCENE_XML[name]), W, H, spp)
+            ctx = hs.preprocess()
+        finally:
+            del os.environ["NORI_HIP_PIPELINE"], os.environ["NORI_HIP_POOL"]
+        ctx.reset_stats(); ctx.render(0, spp)
+        films.append(ctx.read_film()); stats.append(ctx.stats())
+        hs.close()
+    for f, st in zip(films[1:], stats[1:]):
+        assert np.array_equal(f[:, :, 3], films[0][:, :, 3])
+        assert np.allclose(f, films[0], rtol=1e-4, atol=1e-5)
+        for k in ("camera_samples", "closest_rays", "shadow_rays", "invalid_samples"):
+            assert st[k] == stats[0][k], (k, st[k], stats[0][k])
+    assert stats[0]["camera_samples"] == W * H * spp and stats[0]["iterations"] > 10
+
+
 def test_filter_pass_matches_oracle(loaded):
     W, H = 48, 40
     hs, ctx = loaded("cbox", W, H)
