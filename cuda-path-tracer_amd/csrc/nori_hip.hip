@@ -18,6 +18,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "nori_device.h"
 
 #pragma clang fp contract(off)
@@ -282,26 +283,49 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, RenderJob
     if ((threadIdx.x & 63) == 0 && (v0 | v1)) { atomicAdd(&stats->samples, v0); atomicAdd(&stats->invalid, v1); }
 }
 
-template <bool ANY>
-__global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, const unsigned int *n_ptr, unsigned int *head, DevStats *stats) {
+// Per-lane traversal stack with its first LDS_DEPTH entries in LDS ([entry][lane] layout: the 64 lanes of a wave
+// touch 64 consecutive 8-byte words, conflict-free for ds_read/write_b64) and the rare deeper entries in scratch.
+#define LDS_DEPTH 12
+struct LdsStack {
+    uint2 *base;                        // this lane's column: base[entry * 64]
+    uint2 spill[ND_STACK - LDS_DEPTH];
+    __device__ __forceinline__ void push(int i, uint2 v) { if (i < LDS_DEPTH) base[i * 64] = v; else spill[i - LDS_DEPTH] = v; }
+    __device__ __forceinline__ uint2 pop(int i) const { return (i < LDS_DEPTH) ? base[i * 64] : spill[i - LDS_DEPTH]; }
+};
+
+// Trace stage.  The queue is cut into one contiguous chunk per wave; a wave walks its chunk with a wave-uniform
+// cursor and hands the next indices to whichever lanes are idle (ballot + prefix count, no global atomics), so a
+// lane whose ray has finished is refilled at the next loop trip while its neighbours keep traversing.
+template <bool ANY, bool USE_LDS>
+__global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, const unsigned int *n_ptr, DevStats *stats) {
+    __shared__ uint2 lds_stack[USE_LDS ? 4 * LDS_DEPTH * 64 : 1];
     const unsigned int n = *n_ptr;
-    ScratchStack stk;
+    const unsigned int lane = threadIdx.x & 63u;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int chunk = (((n + n_waves - 1) / n_waves) + 63u) & ~63u;
+    unsigned int cursor = wave * chunk;                                  // wave-uniform
+    const unsigned int end = (cursor + chunk < n) ? cursor + chunk : n;
+    if (cursor >= n) return;
+    typename std::conditional<USE_LDS, LdsStack, ScratchStack>::type stk;
+    if constexpr (USE_LDS) stk.base = lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0;
-    bool have = false, exhausted = false; unsigned int slot = 0;
+    bool have = false; unsigned int slot = 0;
     uint32_t n_boxes = 0, n_prims = 0, n_rays = 0;
     for (;;) {
-        if (!have && !exhausted) {
-            unsigned int idx = atomicAdd(head, 1u);
-            if (idx < n) {
+        const unsigned long long idle = __ballot(!have);
+        if (idle && cursor < end) {
+            const unsigned int idx = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) idle, 0u));
+            if (!have && idx < end) {
                 slot = queue[idx];
                 float4 ro = ANY ? pool.sh_o[slot] : pool.ray_o[slot], rd = ANY ? pool.sh_d[slot] : pool.ray_d[slot];
                 Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
                 if (!(r.maxt < r.mint)) n_rays++;
                 have = true;
                 if (!tv.begin(sc, r, n_boxes)) tv.cur = ND_DONE;
-            } else exhausted = true;
+            }
+            cursor += (unsigned int) __popcll(idle);
         }
-        if (__ballot(have) == 0ull) { if (__ballot(!exhausted) == 0ull) break; continue; }
+        if (__ballot(have) == 0ull) break;                               // chunk consumed and nothing in flight
         if (have) {
             while (!(tv.cur & NORI_HIP_LEAF_BIT) && tv.cur != ND_DONE) tv.inner_step(sc, stk, n_boxes);
             if (tv.cur != ND_DONE) tv.leaf_step(sc, stk, n_prims);
@@ -325,7 +349,51 @@ __global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, flo
     }
     unsigned long long v[3] = {n_rays, n_boxes, n_prims};
     for (int k = 0; k < 3; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
-    if ((threadIdx.x & 63) == 0 && v[0]) { atomicAdd(ANY ? &stats->shadow : &stats->closest, v[0]); atomicAdd(&stats->nodes, v[1]); atomicAdd(&stats->prims, v[2]); }
+    if (lane == 0 && (v[0] | v[1])) { atomicAdd(ANY ? &stats->shadow : &stats->closest, v[0]); atomicAdd(&stats->nodes, v[1]); atomicAdd(&stats->prims, v[2]); }
+}
+
+// Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
+// stage launch per bounce would be mostly launch latency.  Each lane takes one surviving slot (its closest hit is
+// already in the pool) and runs its path to the end.
+__global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, unsigned int *n_ptr, DevStats *stats) {
+    const unsigned int n = *n_ptr;
+    ScratchStack stk; Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned int slot = queue[i];
+        float4 L = pool.li[slot];
+        unsigned int flags = __float_as_uint(L.w);
+        if (!(flags & PF_ACTIVE) || (flags & PF_ENDING)) continue;       // already splatted by the shadow stage
+        uint4 h = pool.hit[slot];
+        float4 P = pool.pix[slot];
+        PathState ps; ps.li = f3(L.x, L.y, L.z);
+        if (h.x != 0xffffffffu) {
+            float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; uint4 R = pool.rng[slot];
+            ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
+            ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
+            Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
+            Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
+            for (;;) {
+                ShadeOut so;
+                shade_hit(sc, ps, rng, hit, so);
+                if (so.has_shadow) {
+                    Hit sh; ctr.shadow++;
+                    if (!trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
+                }
+                if (so.end) break;
+                ctr.closest++;
+                if (!trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims)) break;
+            }
+        }
+        unsigned int pxy = __float_as_uint(P.z);
+        if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
+        pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+    }
+    unsigned long long v[5] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
+    for (int k = 0; k < 5; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
+    if ((threadIdx.x & 63) == 0 && (v[0] | v[1] | v[2])) {
+        atomicAdd(&stats->closest, v[0]); atomicAdd(&stats->shadow, v[1]); atomicAdd(&stats->invalid, v[2]); atomicAdd(&stats->nodes, v[3]); atomicAdd(&stats->prims, v[4]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { }    // n_ptr is cleared by the host-side memset that follows this launch
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -415,6 +483,8 @@ struct NoriHipContext {
     unsigned int *d_queue[2] = {nullptr, nullptr}, *d_qshadow = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
+    bool lds_stack = true;            // traversal stack of the trace stages: LDS (+ scratch spill) or scratch only
+    unsigned int finish_below = 32768;
     void free_scene() {
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
@@ -446,6 +516,8 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipMemset(c->d_stats, 0, sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) c->pipeline = (std::string(e) == "mega") ? 0 : 1;
+    if (const char *e = getenv("NORI_HIP_STACK")) c->lds_stack = std::string(e) != "scratch";
+    if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     c->pool_slots = 1u << 20;
     if (const char *e = getenv("NORI_HIP_POOL")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) c->pool_slots = (unsigned int) v; }
     HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
@@ -631,29 +703,45 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     }
     unsigned int P = ctx->pool_slots;
     if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
-    const unsigned trace_blocks = (unsigned) ctx->n_cus * 8u;
-    const unsigned shade_blocks = std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * 16u);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, ctx->d_queue[0], P, ctx->d_cnt);
+    const bool lds = ctx->lds_stack;
+    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below, P);
+    unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     int cur = 0; uint64_t it = 0;
     for (;; ++it) {
         WfCounters *c = ctx->d_cnt;
+        // grids sized by the (stale, hence conservative) live count: up to two rounds of resident waves
+        const unsigned trace_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 16u));
+        const unsigned shade_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 16u));
         hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c, cur);
         hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, job, ctx->d_film, (const unsigned int *) ctx->d_queue[cur],
                            (const unsigned int *) &c->n_active[cur], ctx->d_queue[1 - cur], &c->n_active[1 - cur], ctx->d_qshadow, &c->n_shadow, ctx->d_counter, ctx->d_stats);
-        hipLaunchKernelGGL(k_trace_queue<true>, dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qshadow,
-                           (const unsigned int *) &c->n_shadow, &c->head_shadow, ctx->d_stats);
-        hipLaunchKernelGGL(k_trace_queue<false>, dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_queue[1 - cur],
-                           (const unsigned int *) &c->n_active[1 - cur], &c->head_extend, ctx->d_stats);
+        if (lds) {
+            hipLaunchKernelGGL((k_trace_queue<true, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qshadow, (const unsigned int *) &c->n_shadow, ctx->d_stats);
+            hipLaunchKernelGGL((k_trace_queue<false, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_queue[1 - cur], (const unsigned int *) &c->n_active[1 - cur], ctx->d_stats);
+        } else {
+            hipLaunchKernelGGL((k_trace_queue<true, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qshadow, (const unsigned int *) &c->n_shadow, ctx->d_stats);
+            hipLaunchKernelGGL((k_trace_queue<false, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_queue[1 - cur], (const unsigned int *) &c->n_active[1 - cur], ctx->d_stats);
+        }
         HIPCHK(hipGetLastError());
-        // the number of live slots comes back through a 4-deep ring of pinned words, so the host runs at most three
-        // iterations ahead of the device and never waits on the iteration it has just queued
+        // the live count comes back through a 4-deep ring of pinned words, so the host runs at most three iterations
+        // ahead of the device and never waits on the iteration it has just queued
         HIPCHK(hipMemcpyAsync(&ctx->h_ring[it & 3], &c->n_active[1 - cur], sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ring_ev[it & 3], ctx->stream));
         cur = 1 - cur;
         if (it >= 3) {
             HIPCHK(hipEventSynchronize(ctx->ring_ev[(it - 3) & 3]));
-            if (ctx->h_ring[(it - 3) & 3] == 0) break;
+            n_upper = ctx->h_ring[(it - 3) & 3];
+            if (n_upper == 0) break;
+            if (n_upper < finish_below) {
+                // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
+                hipLaunchKernelGGL(k_finish, dim3(std::max(1u, (n_upper + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film,
+                                   (const unsigned int *) ctx->d_queue[cur], &c->n_active[cur], ctx->d_stats);
+                HIPCHK(hipGetLastError());
+                ++it;
+                break;
+            }
         }
         if (it > (1ull << 24)) return fail(NORI_HIP_EDEVICE, "wavefront loop did not terminate");
     }

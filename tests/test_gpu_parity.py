@@ -138,14 +138,18 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
     many regeneration rounds and a long tail."""
     W, H, spp = 80, 56, 6
     films, stats = [], []
-    for mode, pool in (("wavefront", "4096"), ("wavefront", "1048576"), ("mega", "4096")):
-        os.environ["NORI_HIP_PIPELINE"] = mode
-        os.environ["NORI_HIP_POOL"] = pool
+    configs = [dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="4096"),
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="4096", NORI_HIP_STACK="scratch", NORI_HIP_FINISH="0"),
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="1048576"),
+               dict(NORI_HIP_PIPELINE="mega")]
+    for env in configs:
+        os.environ.update(env)
         try:
             hs = NH.HostScene(os.path.join(SCENES, SCENE_XML[name]), W, H, spp)
             ctx = hs.preprocess()
         finally:
-            del os.environ["NORI_HIP_PIPELINE"], os.environ["NORI_HIP_POOL"]
+            for k in env:
+                del os.environ[k]
         ctx.reset_stats(); ctx.render(0, spp)
         films.append(ctx.read_film()); stats.append(ctx.stats())
         hs.close()
