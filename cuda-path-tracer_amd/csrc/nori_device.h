@@ -100,27 +100,25 @@ struct DevScene {
 struct Ray { F3 o, d; float mint, maxt; };
 struct Hit { uint32_t pos; float t, u, v; };       // pos = record index in leaf order; 0xffffffff = miss
 
-// include/nori/bbox.h:336-363.  `near_out` is the entry distance; the caller re-checks it against a shrunken
-// maxt when the node is popped, which is exactly what re-running the reference's test then would decide.
+// include/nori/bbox.h:336-363, written without branches: every lane of a wave runs the same instructions and the
+// per-axis rejections are accumulated in `ok` (nearT only grows and farT only shrinks, so an early "nearT > farT"
+// of the reference also fails every later check; the values that reach `near_out` on a hit are the reference's).
+// `near_out` is the entry distance; the caller re-checks it against a shrunken maxt when the node is popped, which
+// is exactly what re-running the reference's test then would decide.
+#define ND_SLAB_AXIS(O, D, R, MN, MX) { \
+    float t1 = ((MN) - (O)) * (R), t2 = ((MX) - (O)) * (R); \
+    bool sw = t1 > t2; float lo = sw ? t2 : t1, hi = sw ? t1 : t2; \
+    float nn = (lo < nearT) ? nearT : lo, ff = (farT < hi) ? farT : hi; \
+    bool z = ((D) == 0); \
+    nearT = z ? nearT : nn; farT = z ? farT : ff; \
+    ok = ok & (z ? !((O) < (MN) || (O) > (MX)) : (nearT <= farT)); }
 __device__ __forceinline__ bool slab(const float *bmin, const float *bmax, F3 o, F3 d, F3 rcp, float mint, float maxt, float &near_out) {
-    float nearT = -ND_INF, farT = ND_INF;
-    {
-        if (d.x == 0) { if (o.x < bmin[0] || o.x > bmax[0]) return false; }
-        else { float t1 = (bmin[0] - o.x) * rcp.x, t2 = (bmax[0] - o.x) * rcp.x; if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
-               nearT = (t1 < nearT) ? nearT : t1; farT = (farT < t2) ? farT : t2; if (!(nearT <= farT)) return false; }
-    }
-    {
-        if (d.y == 0) { if (o.y < bmin[1] || o.y > bmax[1]) return false; }
-        else { float t1 = (bmin[1] - o.y) * rcp.y, t2 = (bmax[1] - o.y) * rcp.y; if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
-               nearT = (t1 < nearT) ? nearT : t1; farT = (farT < t2) ? farT : t2; if (!(nearT <= farT)) return false; }
-    }
-    {
-        if (d.z == 0) { if (o.z < bmin[2] || o.z > bmax[2]) return false; }
-        else { float t1 = (bmin[2] - o.z) * rcp.z, t2 = (bmax[2] - o.z) * rcp.z; if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
-               nearT = (t1 < nearT) ? nearT : t1; farT = (farT < t2) ? farT : t2; if (!(nearT <= farT)) return false; }
-    }
+    float nearT = -ND_INF, farT = ND_INF; bool ok = true;
+    ND_SLAB_AXIS(o.x, d.x, rcp.x, bmin[0], bmax[0])
+    ND_SLAB_AXIS(o.y, d.y, rcp.y, bmin[1], bmax[1])
+    ND_SLAB_AXIS(o.z, d.z, rcp.z, bmin[2], bmax[2])
     near_out = nearT;
-    return mint <= farT && nearT <= maxt;
+    return ok & (mint <= farT) & (nearT <= maxt);
 }
 
 #ifndef ND_STACK
@@ -131,22 +129,30 @@ __device__ __forceinline__ bool slab(const float *bmin, const float *bmax, F3 o,
 // (left subtree first, right pushed), so closest-hit ties resolve to the same primitive.
 // Stack entries are (child reference, entry distance); the stack type decides where they live (LDS / scratch).
 //
-// Trav is the traversal as a resumable state machine: begin() tests the root box, inner_step() visits one 64-byte
-// node, leaf_step() tests the records of one leaf and pops.  Persistent kernels interleave these steps with
-// fetching new rays for lanes that have finished ("while-while" traversal with dynamic fetch).
-#define ND_DONE 0x7fffffffu        /* cur value of a finished traversal (never a valid inner index, no leaf bit) */
+// Trav is the traversal as a resumable state machine whose steps contain no data-dependent loops: box_step()
+// visits one 64-byte node, prim_step() tests ONE leaf record, pop_step() takes one entry off the stack.  A kernel
+// runs the steps for the lanes that are in the matching state; the queue kernels choose per trip which step is
+// worth running for the wave (see k_trace_queue).  `cur` encodes the state:
+//   < ND_POP            inner node index            (box_step)
+//   ND_POP              needs an entry of the stack (pop_step)
+//   ND_DONE             traversal finished
+//   NORI_HIP_LEAF_BIT|p next leaf record to test    (prim_step)
+#define ND_POP  0x7ffffffeu
+#define ND_DONE 0x7fffffffu
 
 template <bool ANY> struct Trav {
     F3 o, d, rcp; float mint, maxt; uint32_t cur; int sp; Hit hit; bool found;
+    bool special;      // a direction component is zero, denormal or NaN: box tests take the general path
 
-    template <typename StackT> __device__ __forceinline__ void pop(StackT &stk) {
-        // an entry is skipped when its box no longer passes with the current maxt
-        while (sp > 0) { uint2 e = stk.pop(--sp); if (__uint_as_float(e.y) <= maxt) { cur = e.x; return; } }
-        cur = ND_DONE;
-    }
+    __device__ __forceinline__ bool at_inner() const { return cur < ND_POP; }
+    __device__ __forceinline__ bool at_leaf() const { return (cur & NORI_HIP_LEAF_BIT) != 0u; }
+    __device__ __forceinline__ bool at_pop() const { return cur == ND_POP; }
+    __device__ __forceinline__ bool done() const { return cur == ND_DONE; }
+
     // false: the ray ends without entering the tree
     __device__ __forceinline__ bool begin(const DevScene &sc, const Ray &r, uint32_t &n_boxes) {
         o = r.o; d = r.d; mint = r.mint; maxt = r.maxt; sp = 0; found = false; cur = ND_DONE;
+        special = !(fabsf(d.x) >= 1.17549435e-38f && fabsf(d.y) >= 1.17549435e-38f && fabsf(d.z) >= 1.17549435e-38f);
         hit.pos = 0xffffffffu; hit.t = ND_INF; hit.u = hit.v = 0.f;
         if (mint == ND_EPS) {                       // adaptive epsilon, src/bvh.cpp:411-412
             float m = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z)));
@@ -159,73 +165,97 @@ template <bool ANY> struct Trav {
         cur = sc.root;
         return true;
     }
-    template <typename StackT> __device__ __forceinline__ void inner_step(const DevScene &sc, StackT &stk, uint32_t &n_boxes) {
+    // an entry is skipped when its box no longer passes with the current maxt (then the lane stays in ND_POP)
+    template <typename StackT> __device__ __forceinline__ void pop_step(StackT &stk) {
+        if (sp == 0) { cur = ND_DONE; return; }
+        uint2 e = stk.pop(--sp);
+        cur = (__uint_as_float(e.y) <= maxt) ? e.x : ND_POP;
+    }
+    // The same node visit for rays whose direction components are all normal numbers (`special` false).  Then every
+    // reciprocal is finite, no product can be NaN, and the reference's compare-and-select chains (include/nori/
+    // bbox.h:345-358) return exactly min/max of their operands; its per-axis "nearT > farT" exits are implied by the
+    // final comparison because nearT only grows and farT only shrinks.  Same decisions and entry distances (up to
+    // the sign of a zero, which no comparison sees), a third of the instructions.
+    template <typename StackT> __device__ __forceinline__ void box_step_fast(const DevScene &sc, StackT &stk, uint32_t &n_boxes) {
+        const float4 *q = reinterpret_cast<const float4 *>(sc.nodes + cur);
+        float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+        uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+        n_boxes += 2;
+        float ax1 = (n0.x - o.x) * rcp.x, ax2 = (n0.w - o.x) * rcp.x;
+        float ay1 = (n0.y - o.y) * rcp.y, ay2 = (n1.x - o.y) * rcp.y;
+        float az1 = (n0.z - o.z) * rcp.z, az2 = (n1.y - o.z) * rcp.z;
+        float bx1 = (n1.z - o.x) * rcp.x, bx2 = (n2.y - o.x) * rcp.x;
+        float by1 = (n1.w - o.y) * rcp.y, by2 = (n2.z - o.y) * rcp.y;
+        float bz1 = (n2.x - o.z) * rcp.z, bz2 = (n2.w - o.z) * rcp.z;
+        float nl = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax1, ax2), __builtin_fminf(ay1, ay2)), __builtin_fminf(az1, az2));
+        float fl = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax1, ax2), __builtin_fmaxf(ay1, ay2)), __builtin_fmaxf(az1, az2));
+        float nrr = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(bx1, bx2), __builtin_fminf(by1, by2)), __builtin_fminf(bz1, bz2));
+        float fr = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx1, bx2), __builtin_fmaxf(by1, by2)), __builtin_fmaxf(bz1, bz2));
+        bool hl = (nl <= fl) & (mint <= fl) & (nl <= maxt);
+        bool hr = (nrr <= fr) & (mint <= fr) & (nrr <= maxt) & (right != NORI_HIP_NO_CHILD);
+        if (hl & hr) stk.push(sp++, make_uint2(right, __float_as_uint(nrr)));
+        cur = hl ? left : (hr ? right : ND_POP);
+    }
+    template <typename StackT> __device__ __forceinline__ void box_step(const DevScene &sc, StackT &stk, uint32_t &n_boxes) {
         const float4 *q = reinterpret_cast<const float4 *>(sc.nodes + cur);
         float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
         float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
         float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
         uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
-        float nl, nrr = 0.f;
+        float nl, nrr;
         n_boxes += 2;
         bool hl = slab(lmin, lmax, o, d, rcp, mint, maxt, nl);
-        bool hr = (right != NORI_HIP_NO_CHILD) && slab(rmin, rmax, o, d, rcp, mint, maxt, nrr);
-        if (hl) { if (hr) { stk.push(sp++, make_uint2(right, __float_as_uint(nrr))); } cur = left; }
-        else if (hr) cur = right;
-        else pop(stk);
+        bool hr = slab(rmin, rmax, o, d, rcp, mint, maxt, nrr) & (right != NORI_HIP_NO_CHILD);
+        if (hl & hr) stk.push(sp++, make_uint2(right, __float_as_uint(nrr)));
+        cur = hl ? left : (hr ? right : ND_POP);
     }
-    template <typename StackT> __device__ __forceinline__ void leaf_step(const DevScene &sc, StackT &stk, uint32_t &n_prims) {
-        uint32_t pos = cur & 0x7fffffffu;
-        uint32_t flags;
-        do {
-            const float4 *r = sc.prims + 3 * (size_t) pos;
-            float4 A = r[0], B = r[1], C = r[2];
-            flags = __float_as_uint(C.z);
-            n_prims++;
-            float t = 0.f, u = 0.f, v = 0.f; bool h = false;
-            if (!(flags & 0x40000000u)) {
-                // Mesh::rayIntersect, src/mesh.cpp:84-121
-                F3 p0 = f3(A.x, A.y, A.z), edge1 = f3(A.w, B.x, B.y), edge2 = f3(B.z, B.w, C.x);
-                F3 pvec = cross(d, edge2);
-                float det = dot(edge1, pvec);
-                if (!(det > -1e-8f && det < 1e-8f)) {
-                    float inv_det = 1.0f / det;
-                    F3 tvec = o - p0;
-                    u = dot(tvec, pvec) * inv_det;
-                    if (!(u < 0.0f || u > 1.0f)) {
-                        F3 qvec = cross(tvec, edge1);
-                        v = dot(d, qvec) * inv_det;
-                        if (!(v < 0.0f || u + v > 1.0f)) {
-                            t = dot(edge2, qvec) * inv_det;
-                            h = t >= mint && t <= maxt;
-                        }
-                    }
-                }
-            } else {
-                // Sphere::rayIntersect, src/sphere.cpp:42-113
-                F3 c = f3(A.x, A.y, A.z); float rad = A.w;
-                float Bq = 2 * dot(o - c, d);
-                float Cq = ((-rad * rad + dot(c, c)) + dot(o, o)) - 2 * dot(c, o);
-                float discr = Bq * Bq - 4 * Cq;
-                if (discr > 0) {
-                    float sq = nd_sqrt(discr);
-                    float t1 = (-Bq + sq) * 0.5f, t2 = (-Bq - sq) * 0.5f;
-                    bool v1 = t1 >= mint && t1 <= maxt, v2 = t2 >= mint && t2 <= maxt;
-                    if (v1 && v2) { t = (t2 < t1) ? t2 : t1; h = true; }
-                    else if (v1) { t = t1; h = true; }
-                    else if (v2) { t = t2; h = true; }
-                } else if (discr == 0) {
-                    float tt = -Bq * 0.5f;
-                    if (tt >= mint && tt < maxt) { t = tt; h = true; }
-                }
+    // one record of the current leaf; afterwards the lane is at the next record, in ND_POP (leaf finished) or done
+    __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) {
+        const uint32_t pos = cur & 0x7fffffffu;
+        const float4 *r = sc.prims + 3 * (size_t) pos;
+        float4 A = r[0], B = r[1], C = r[2];
+        const uint32_t flags = __float_as_uint(C.z);
+        n_prims++;
+        float t = 0.f, u = 0.f, v = 0.f; bool h = false;
+        if (!(flags & 0x40000000u)) {
+            // Mesh::rayIntersect, src/mesh.cpp:84-121: same arithmetic, the early returns folded into one predicate
+            F3 p0 = f3(A.x, A.y, A.z), edge1 = f3(A.w, B.x, B.y), edge2 = f3(B.z, B.w, C.x);
+            F3 pvec = cross(d, edge2);
+            float det = dot(edge1, pvec);
+            bool ok = !(det > -1e-8f && det < 1e-8f);
+            float inv_det = 1.0f / det;
+            F3 tvec = o - p0;
+            u = dot(tvec, pvec) * inv_det;
+            ok = ok & !(u < 0.0f || u > 1.0f);
+            F3 qvec = cross(tvec, edge1);
+            v = dot(d, qvec) * inv_det;
+            ok = ok & !(v < 0.0f || u + v > 1.0f);
+            t = dot(edge2, qvec) * inv_det;
+            h = ok & (t >= mint) & (t <= maxt);
+        } else {
+            // Sphere::rayIntersect, src/sphere.cpp:42-113
+            F3 c = f3(A.x, A.y, A.z); float rad = A.w;
+            float Bq = 2 * dot(o - c, d);
+            float Cq = ((-rad * rad + dot(c, c)) + dot(o, o)) - 2 * dot(c, o);
+            float discr = Bq * Bq - 4 * Cq;
+            if (discr > 0) {
+                float sq = nd_sqrt(discr);
+                float t1 = (-Bq + sq) * 0.5f, t2 = (-Bq - sq) * 0.5f;
+                bool v1 = t1 >= mint && t1 <= maxt, v2 = t2 >= mint && t2 <= maxt;
+                if (v1 && v2) { t = (t2 < t1) ? t2 : t1; h = true; }
+                else if (v1) { t = t1; h = true; }
+                else if (v2) { t = t2; h = true; }
+            } else if (discr == 0) {
+                float tt = -Bq * 0.5f;
+                if (tt >= mint && tt < maxt) { t = tt; h = true; }
             }
-            if (h) {
-                found = true;
-                if (ANY) { cur = ND_DONE; return; }
-                maxt = t; hit.pos = pos; hit.t = t; hit.u = u; hit.v = v;
-            }
-            pos++;
-        } while (!(flags & 0x80000000u));
-        pop(stk);
+        }
+        cur = (flags & 0x80000000u) ? ND_POP : (NORI_HIP_LEAF_BIT | (pos + 1u));
+        if (h) {
+            found = true;
+            if (ANY) { cur = ND_DONE; return; }
+            maxt = t; hit.pos = pos; hit.t = t; hit.u = u; hit.v = v;
+        }
     }
 };
 
@@ -234,9 +264,10 @@ template <bool ANY, typename StackT>
 __device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
     Trav<ANY> tv;
     if (tv.begin(sc, ray_in, n_nodes)) {
-        while (tv.cur != ND_DONE) {
-            while (!(tv.cur & NORI_HIP_LEAF_BIT) && tv.cur != ND_DONE) tv.inner_step(sc, stk, n_nodes);
-            if (tv.cur != ND_DONE) tv.leaf_step(sc, stk, n_prims);
+        while (!tv.done()) {
+            if (tv.at_inner()) { if (tv.special) tv.box_step(sc, stk, n_nodes); else tv.box_step_fast(sc, stk, n_nodes); }
+            if (tv.at_leaf()) tv.prim_step(sc, n_prims);
+            if (tv.at_pop()) tv.pop_step(stk);
         }
     }
     hit = tv.hit;

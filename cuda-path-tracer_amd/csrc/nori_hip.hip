@@ -31,7 +31,13 @@ thread_local std::string g_err;
 int fail(int code, const std::string &m) { g_err = m; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(NORI_HIP_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-struct DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims; };
+// Atomics that hit the same 256-byte line are served one after the other by the memory side, about 11 ns each on
+// MI355X (scratch/atombench.hip), whatever their address within the line; distinct lines proceed in parallel.
+// Every counter the kernels bump therefore sits on a line of its own, and the hot ones are striped over ND_STRIPES
+// lines that the reader sums.
+#define ND_STRIPES 32
+struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims; unsigned long long prof[2][10]; };
+__device__ __forceinline__ DevStats *my_stats(DevStats *stats) { return stats + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ND_STRIPES - 1)); }
 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *rays, size_t n, int any_hit, NoriHipHit *hits, float *full) {
@@ -118,33 +124,48 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
     return true;
 }
 
+// Work items are handed out ND_WORK_GRAB at a time per wave (one atomic by one lane) and dealt to the lanes whose
+// path has ended with a ballot + prefix count, so the global counter sees one atomic per ND_WORK_GRAB samples.
+#define ND_WORK_GRAB 256u
 __global__ __launch_bounds__(256) void k_render(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats) {
     ScratchStack stk;
     Counters ctr = {0, 0, 0, 0};
     unsigned int n_samples = 0, n_invalid = 0;
     PathState ps; Pcg32 rng; F2 pixel_sample = f2(0.f, 0.f); int px = 0, py = 0;
-    bool alive = false, exhausted = false;
+    bool alive = false;
+    const unsigned int lane = threadIdx.x & 63u;
     const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
     const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
+    unsigned long long cursor = 0, end = 0;                               // wave-uniform: work items [cursor, end) are ours
+    bool exhausted = false;                                               // wave-uniform
     for (;;) {
-        if (!alive && !exhausted) {
-            // draw the next work item (hipcc merges the per-lane atomics of a wave into one)
-            for (;;) {
-                unsigned long long w = atomicAdd(work_counter, 1ull);
-                if (w >= padded_total) { exhausted = true; break; }
-                int s; work_to_sample(job, w, px, py, s);
-                if (px >= job.x0 + job.tw || py >= job.y0 + job.th) continue;          // padding of edge patches
-                rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) s);
-                F2 j = rng.next2D();
-                pixel_sample = f2((float) px + j.x, (float) py + j.y);
-                (void) rng.next2D();                                                  // aperture sample, src/render.cpp:86
-                Ray r; camera_ray(sc, pixel_sample, r);
-                path_init(ps, r);
-                alive = true; n_samples++;
-                break;
+        const unsigned long long dead = __ballot(!alive);
+        if (dead && !(exhausted && cursor >= end)) {
+            if (cursor >= end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(work_counter, (unsigned long long) ND_WORK_GRAB);
+                base = ((unsigned long long) __builtin_amdgcn_readfirstlane((unsigned int) (base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned int) base);
+                if (base >= padded_total) exhausted = true;
+                else { cursor = base; end = (base + ND_WORK_GRAB < padded_total) ? base + ND_WORK_GRAB : padded_total; }
+            }
+            if (cursor < end) {
+                const unsigned long long w = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) dead, 0u));
+                if (!alive && w < end) {
+                    int s; work_to_sample(job, w, px, py, s);
+                    if (px < job.x0 + job.tw && py < job.y0 + job.th) {                   // else: padding of an edge patch
+                        rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) s);
+                        F2 j = rng.next2D();
+                        pixel_sample = f2((float) px + j.x, (float) py + j.y);
+                        (void) rng.next2D();                                              // aperture sample, src/render.cpp:86
+                        Ray r; camera_ray(sc, pixel_sample, r);
+                        path_init(ps, r);
+                        alive = true; n_samples++;
+                    }
+                }
+                cursor += (unsigned long long) __popcll(dead);
             }
         }
-        if (__ballot(alive) == 0ull) break;                                           // whole wave out of work
+        if (__ballot(alive) == 0ull) { if (exhausted && cursor >= end) break; else continue; }
         if (alive) {
             if (!path_bounce(sc, ps, rng, stk, ctr)) {
                 if (!film_put(sc, film, pixel_sample, px, py, ps.li)) n_invalid++;
@@ -152,16 +173,17 @@ __global__ __launch_bounds__(256) void k_render(DevScene sc, RenderJob job, floa
             }
         }
     }
-    // per-wave reduction of the counters, one atomic per wave
+    // per-wave reduction of the counters, one set of atomics per wave on the wave's stripe
     unsigned long long v[6] = {n_samples, ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
     for (int k = 0; k < 6; ++k) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         v[k] = x;
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&stats->samples, v[0]); atomicAdd(&stats->closest, v[1]); atomicAdd(&stats->shadow, v[2]);
-        atomicAdd(&stats->invalid, v[3]); atomicAdd(&stats->nodes, v[4]); atomicAdd(&stats->prims, v[5]);
+    if (lane == 0) {
+        DevStats *st = my_stats(stats);
+        atomicAdd(&st->samples, v[0]); atomicAdd(&st->closest, v[1]); atomicAdd(&st->shadow, v[2]);
+        atomicAdd(&st->invalid, v[3]); atomicAdd(&st->nodes, v[4]); atomicAdd(&st->prims, v[5]);
     }
 }
 
@@ -191,152 +213,212 @@ struct Pool {
     float4 *sh_d;      // shadow ray d.xyz, maxt
     float4 *sh_c;      // NEE contribution rgb if unoccluded
 };
-struct WfCounters { unsigned int n_active[2]; unsigned int n_shadow; unsigned int head_extend; unsigned int head_shadow; unsigned int pad[3]; };
+
+// Queue counters, one per 256-byte line (see DevStats): the two live-slot counts, the shadow count, and the heads
+// of the trace stages, which are striped: a queue of n entries is cut into ND_SEG equal segments with a head each,
+// a wave starts at segment (wave % ND_SEG) and moves on to the next one when its segment is used up.
+#define ND_SEG 32
+#define ND_LINE 64                              /* unsigned ints per 256-byte line */
+struct WfCounters { unsigned int v[(3 + 2 * ND_SEG) * ND_LINE]; };
+#define CN_ACTIVE(c, i)  ((c)->v[(i) * ND_LINE])
+#define CN_SHADOW(c)     ((c)->v[2 * ND_LINE])
+#define CN_HEAD(c, any, k) ((c)->v[(3 + ((any) ? ND_SEG : 0) + (k)) * ND_LINE])
 
 __global__ void k_pool_init(Pool pool, unsigned int *queue, unsigned int n, WfCounters *cnt) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { queue[i] = i; pool.li[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u)); }
-    if (i == 0) { cnt->n_active[0] = n; cnt->n_active[1] = 0; cnt->n_shadow = 0; cnt->head_extend = 0; cnt->head_shadow = 0; }
+    if (i < 3 + 2 * ND_SEG) cnt->v[i * ND_LINE] = (i == 0) ? n : 0u;
 }
-__global__ void k_iter_begin(WfCounters *cnt, int cur) { cnt->n_active[1 - cur] = 0; cnt->n_shadow = 0; cnt->head_extend = 0; cnt->head_shadow = 0; }
+__global__ void k_iter_begin(WfCounters *cnt, int cur) {
+    unsigned int i = threadIdx.x;
+    if (i < 3 + 2 * ND_SEG && i != (unsigned int) cur) cnt->v[i * ND_LINE] = 0u;       // everything except the input count
+}
 
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, RenderJob job, float4 *film, const unsigned int *q_in, const unsigned int *n_in_ptr,
-                                               unsigned int *q_next, unsigned int *n_next, unsigned int *q_shadow, unsigned int *n_shadow,
-                                               unsigned long long *work_counter, DevStats *stats) {
-    const unsigned int n_in = *n_in_ptr;
+// Shade stage.  Each block owns a contiguous run of the input queue and walks it twice:
+//   pass A  shades the hits (emission+MIS, roulette, BSDF sample, emitter sample), splats finished paths, and leaves
+//           one flag word per queue position (regenerate / has a shadow ray / goes on)
+//   then ONE set of three atomics per block reserves the block's camera samples and its room in the two output
+//           queues (per-wave totals are combined through LDS)
+//   pass B  regenerates the freed slots from the reserved work items (src/render.cpp:83-98) and writes the queues
+enum { SF_REGEN = 1u, SF_SHADOW = 2u, SF_KEEP = 4u };
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, RenderJob job, float4 *film, const unsigned int *q_in, unsigned int *q_next, unsigned int *q_shadow,
+                                               unsigned int *flag_buf, WfCounters *cnt, int cur, unsigned long long *work_counter, DevStats *stats) {
+    __shared__ unsigned int w_tot[4][3];
+    __shared__ unsigned long long b_work; __shared__ unsigned int b_next, b_shadow;
+    const unsigned int n_in = CN_ACTIVE(cnt, cur);
+    const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
     const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
-    unsigned int n_samples = 0, n_invalid = 0;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
-        const unsigned int slot = q_in[i];
-        float4 L = pool.li[slot];
-        unsigned int flags = __float_as_uint(L.w);
-        bool go_on = false;
-        if (flags & PF_ACTIVE) {
-            uint4 h = pool.hit[slot];
-            float4 P = pool.pix[slot];
-            bool ended = true;
-            PathState ps; ps.li = f3(L.x, L.y, L.z);
-            if (h.x != 0xffffffffu) {
-                float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot];
-                uint4 R = pool.rng[slot];
-                ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
-                ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
-                Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
-                Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
-                ShadeOut so;
-                shade_hit(sc, ps, rng, hit, so);
-                flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
-                if (so.has_shadow) {
-                    pool.sh_o[slot] = make_float4(so.shadow.o.x, so.shadow.o.y, so.shadow.o.z, so.shadow.mint);
-                    pool.sh_d[slot] = make_float4(so.shadow.d.x, so.shadow.d.y, so.shadow.d.z, so.shadow.maxt);
-                    pool.sh_c[slot] = make_float4(so.contrib.x, so.contrib.y, so.contrib.z, 0.f);
-                    q_shadow[atomicAdd(n_shadow, 1u)] = slot;
+    const unsigned int per_block = (((n_in + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
+    const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_in) ? lo + per_block : n_in;
+    unsigned int c_regen = 0, c_shadow = 0, c_keep = 0, n_invalid = 0;      // the first three are wave-uniform
+    for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
+        const unsigned int i = i0 + lane;
+        unsigned int f = 0u;
+        if (i < hi) {
+            const unsigned int slot = q_in[i];
+            const float4 L = pool.li[slot]; const uint4 h = pool.hit[slot]; const float4 P = pool.pix[slot];
+            const float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; const uint4 R = pool.rng[slot];
+            unsigned int flags = __float_as_uint(L.w);
+            f = SF_REGEN;
+            if (flags & PF_ACTIVE) {
+                PathState ps; ps.li = f3(L.x, L.y, L.z);
+                bool ended = true;
+                if (h.x != 0xffffffffu) {
+                    ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
+                    ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
+                    Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
+                    Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
+                    ShadeOut so;
+                    shade_hit(sc, ps, rng, hit, so);
+                    flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
+                    if (so.has_shadow) {
+                        pool.sh_o[slot] = make_float4(so.shadow.o.x, so.shadow.o.y, so.shadow.o.z, so.shadow.mint);
+                        pool.sh_d[slot] = make_float4(so.shadow.d.x, so.shadow.d.y, so.shadow.d.z, so.shadow.maxt);
+                        pool.sh_c[slot] = make_float4(so.contrib.x, so.contrib.y, so.contrib.z, 0.f);
+                        f = SF_SHADOW;
+                    } else f = 0u;
+                    if (!so.end) {
+                        ended = false; f |= SF_KEEP;
+                        pool.ray_o[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.mint);
+                        pool.ray_d[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.ray.maxt);
+                        pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
+                        pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
+                        pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
+                    } else if (so.has_shadow) {
+                        // the path ends, but its last NEE term is still pending: the shadow stage adds it, splats and frees the slot
+                        ended = false; f |= SF_KEEP;
+                        pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);          // maxt < mint: the extend stage skips it
+                        pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags | PF_ENDING));
+                    }
                 }
-                if (!so.end) {
-                    ended = false; go_on = true;
-                    pool.ray_o[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.mint);
-                    pool.ray_d[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.ray.maxt);
-                    pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
+                if (ended) {
+                    unsigned int pxy = __float_as_uint(P.z);
+                    if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
+                    f = SF_REGEN;
+                }
+            }
+            flag_buf[i] = f;
+        }
+        c_regen += (unsigned int) __popcll(__ballot((f & SF_REGEN) != 0u));
+        c_shadow += (unsigned int) __popcll(__ballot((f & SF_SHADOW) != 0u));
+        c_keep += (unsigned int) __popcll(__ballot((f & SF_KEEP) != 0u));
+    }
+    if (lane == 0) { w_tot[wv][0] = c_regen; w_tot[wv][1] = c_shadow; w_tot[wv][2] = c_keep; }
+    __syncthreads();
+    unsigned int t_regen = 0, t_shadow = 0, t_keep = 0, o_regen = 0, o_shadow = 0, o_keep = 0;
+    for (unsigned int k = 0; k < 4; ++k) {
+        if (k == wv) { o_regen = t_regen; o_shadow = t_shadow; o_keep = t_keep; }
+        t_regen += w_tot[k][0]; t_shadow += w_tot[k][1]; t_keep += w_tot[k][2];
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long bw = t_regen ? atomicAdd(work_counter, (unsigned long long) t_regen) : padded_total;
+        unsigned int n_valid = (bw >= padded_total) ? 0u : (unsigned int) ((padded_total - bw < (unsigned long long) t_regen) ? padded_total - bw : (unsigned long long) t_regen);
+        b_work = bw;
+        b_next = (t_keep + n_valid) ? atomicAdd(&CN_ACTIVE(cnt, 1 - cur), t_keep + n_valid) : 0u;
+        b_shadow = t_shadow ? atomicAdd(&CN_SHADOW(cnt), t_shadow) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long base_w = b_work; const unsigned int base_n = b_next, base_s = b_shadow;
+    unsigned int n_samples = 0;
+    for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
+        const unsigned int i = i0 + lane;
+        unsigned int f = 0u, slot = 0u;
+        if (i < hi) { f = flag_buf[i]; slot = q_in[i]; }
+        const unsigned long long m_r = __ballot((f & SF_REGEN) != 0u), m_s = __ballot((f & SF_SHADOW) != 0u), m_k = __ballot((f & SF_KEEP) != 0u);
+        if (f & SF_SHADOW) q_shadow[base_s + o_shadow + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_s >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_s, 0u))] = slot;
+        if (f & SF_KEEP) q_next[base_n + o_keep + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_k, 0u))] = slot;
+        if (f & SF_REGEN) {
+            const unsigned int r = o_regen + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_r >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_r, 0u));
+            const unsigned long long w = base_w + r;
+            if (w < padded_total) {
+                int px, py, sidx; work_to_sample(job, w, px, py, sidx);
+                if (px < job.x0 + job.tw && py < job.y0 + job.th) {
+                    Pcg32 rng; rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) sidx);
+                    F2 j = rng.next2D();
+                    F2 pixel_sample = f2((float) px + j.x, (float) py + j.y);
+                    (void) rng.next2D();
+                    Ray r0; camera_ray(sc, pixel_sample, r0);
+                    pool.ray_o[slot] = make_float4(r0.o.x, r0.o.y, r0.o.z, r0.mint);
+                    pool.ray_d[slot] = make_float4(r0.d.x, r0.d.y, r0.d.z, r0.maxt);
+                    pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
                     pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
-                    pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
-                } else if (so.has_shadow) {
-                    // the path ends, but its last NEE term is still pending: the shadow stage adds it, splats and frees the slot
-                    ended = false; go_on = true;
-                    flags |= PF_ENDING;
-                    pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);          // maxt < mint: the extend stage skips it
-                    pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
+                    pool.pix[slot] = make_float4(pixel_sample.x, pixel_sample.y, __uint_as_float((unsigned int) px | ((unsigned int) py << 16)), 0.f);
+                    pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(PF_ACTIVE | PF_LAST_DELTA));
+                    n_samples++;
+                } else {
+                    // padding of an edge patch: the slot stays in the queue, idle, and draws again in the next iteration
+                    pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);
+                    pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
                 }
-            }
-            if (ended) {
-                unsigned int pxy = __float_as_uint(P.z);
-                if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
-                flags = 0u;
+                q_next[base_n + t_keep + (unsigned int) (w - base_w)] = slot;
+            } else {
+                pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));      // no work left: the slot retires
             }
         }
-        if (!(flags & PF_ACTIVE)) {
-            // regenerate: next camera sample from the global counter (src/render.cpp:83-98)
-            for (;;) {
-                unsigned long long w = atomicAdd(work_counter, 1ull);
-                if (w >= padded_total) { pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u)); break; }
-                int px, py, s; work_to_sample(job, w, px, py, s);
-                if (px >= job.x0 + job.tw || py >= job.y0 + job.th) continue;
-                Pcg32 rng; rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) s);
-                F2 j = rng.next2D();
-                F2 pixel_sample = f2((float) px + j.x, (float) py + j.y);
-                (void) rng.next2D();
-                Ray r; camera_ray(sc, pixel_sample, r);
-                pool.ray_o[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.mint);
-                pool.ray_d[slot] = make_float4(r.d.x, r.d.y, r.d.z, r.maxt);
-                pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
-                pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
-                pool.pix[slot] = make_float4(pixel_sample.x, pixel_sample.y, __uint_as_float((unsigned int) px | ((unsigned int) py << 16)), 0.f);
-                pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(PF_ACTIVE | PF_LAST_DELTA));
-                n_samples++; go_on = true;
-                break;
-            }
-        }
-        if (go_on) q_next[atomicAdd(n_next, 1u)] = slot;
+        o_regen += (unsigned int) __popcll(m_r); o_shadow += (unsigned int) __popcll(m_s); o_keep += (unsigned int) __popcll(m_k);
     }
     unsigned long long v0 = n_samples, v1 = n_invalid;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
-    if ((threadIdx.x & 63) == 0 && (v0 | v1)) { atomicAdd(&stats->samples, v0); atomicAdd(&stats->invalid, v1); }
+    if (lane == 0 && (v0 | v1)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); }
 }
 
 // Per-lane traversal stack with its first LDS_DEPTH entries in LDS ([entry][lane] layout: the 64 lanes of a wave
 // touch 64 consecutive 8-byte words, conflict-free for ds_read/write_b64) and the rare deeper entries in scratch.
 #define LDS_DEPTH 12
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 struct LdsStack {
-    uint2 *base;                        // this lane's column: base[entry * 64]
+    lds_u64 *base;                      // this lane's column: base[entry * 64] (LDS address space, so ds_read/ds_write)
     uint2 spill[ND_STACK - LDS_DEPTH];
-    __device__ __forceinline__ void push(int i, uint2 v) { if (i < LDS_DEPTH) base[i * 64] = v; else spill[i - LDS_DEPTH] = v; }
-    __device__ __forceinline__ uint2 pop(int i) const { return (i < LDS_DEPTH) ? base[i * 64] : spill[i - LDS_DEPTH]; }
+    __device__ __forceinline__ void push(int i, uint2 v) { if (i < LDS_DEPTH) base[i * 64] = ((unsigned long long) v.y << 32) | v.x; else spill[i - LDS_DEPTH] = v; }
+    __device__ __forceinline__ uint2 pop(int i) const {
+        if (i < LDS_DEPTH) { unsigned long long w = base[i * 64]; return make_uint2((unsigned int) w, (unsigned int) (w >> 32)); }
+        return spill[i - LDS_DEPTH];
+    }
 };
 
-// Trace stage.  The queue is cut into one contiguous chunk per wave; a wave walks its chunk with a wave-uniform
-// cursor and hands the next indices to whichever lanes are idle (ballot + prefix count, no global atomics), so a
-// lane whose ray has finished is refilled at the next loop trip while its neighbours keep traversing.
-template <bool ANY, bool USE_LDS>
-__global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, const unsigned int *n_ptr, DevStats *stats) {
+// Trace stage: persistent waves.  A wave takes ND_GRAB consecutive queue entries at a time from the head of its
+// current queue segment (one atomic per grab, issued by one lane) and hands them to whichever lanes are free
+// (ballot + prefix count), so lanes are refilled while their neighbours keep traversing and waves only run dry
+// when the whole queue has been handed out.
+// Every trip of the loop the wave decides, from ballots of the lane states, which traversal step is worth issuing:
+//   retire+refill  when at least `thr.z` lanes have finished (or nothing else is left to do)
+//   box_step       when at least `thr.x` lanes stand at an inner node (or no lane stands at a leaf)
+//   prim_step      when at least `thr.y` lanes stand at a leaf record (or the box step did not run)
+//   pop_step       for the lanes that need a stack entry
+// The steps are straight-line code, so the lanes that take part in a step all do useful work; a lane in the
+// minority state waits a few trips until its kind of step is issued.  At least one step runs per trip, so the loop
+// always makes progress and ends when the queue is consumed and every lane has retired its ray.
+#define ND_GRAB 64u
+template <bool ANY, bool USE_LDS, bool PROF>
+__global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, WfCounters *cnt, int cur, DevStats *stats, int3 thr) {
     __shared__ uint2 lds_stack[USE_LDS ? 4 * LDS_DEPTH * 64 : 1];
-    const unsigned int n = *n_ptr;
+    const unsigned int n = ANY ? CN_SHADOW(cnt) : CN_ACTIVE(cnt, cur);
     const unsigned int lane = threadIdx.x & 63u;
-    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned int chunk = (((n + n_waves - 1) / n_waves) + 63u) & ~63u;
-    unsigned int cursor = wave * chunk;                                  // wave-uniform
-    const unsigned int end = (cursor + chunk < n) ? cursor + chunk : n;
-    if (cursor >= n) return;
+    const unsigned int seg_len = (((n + ND_SEG - 1) / ND_SEG) + 63u) & ~63u;          // entries per segment (the last ones may be short or empty)
+    unsigned int seg = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % ND_SEG, seg_tried = 0;   // wave-uniform
+    unsigned int cursor = 0, end = 0;                                    // wave-uniform: the entries [cursor, end) are ours
+    bool drained = (n == 0);                                             // wave-uniform: every segment has been handed out
     typename std::conditional<USE_LDS, LdsStack, ScratchStack>::type stk;
-    if constexpr (USE_LDS) stk.base = lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
-    Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0;
+    if constexpr (USE_LDS) stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
+    Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
     bool have = false; unsigned int slot = 0;
-    uint32_t n_boxes = 0, n_prims = 0, n_rays = 0;
+    uint32_t n_boxes = 0, n_prims = 0, n_rays = 0, n_invalid = 0;
+    unsigned int pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // PROF only: wave-uniform step statistics
     for (;;) {
-        const unsigned long long idle = __ballot(!have);
-        if (idle && cursor < end) {
-            const unsigned int idx = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) idle, 0u));
-            if (!have && idx < end) {
-                slot = queue[idx];
-                float4 ro = ANY ? pool.sh_o[slot] : pool.ray_o[slot], rd = ANY ? pool.sh_d[slot] : pool.ray_d[slot];
-                Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
-                if (!(r.maxt < r.mint)) n_rays++;
-                have = true;
-                if (!tv.begin(sc, r, n_boxes)) tv.cur = ND_DONE;
-            }
-            cursor += (unsigned int) __popcll(idle);
-        }
-        if (__ballot(have) == 0ull) break;                               // chunk consumed and nothing in flight
-        if (have) {
-            while (!(tv.cur & NORI_HIP_LEAF_BIT) && tv.cur != ND_DONE) tv.inner_step(sc, stk, n_boxes);
-            if (tv.cur != ND_DONE) tv.leaf_step(sc, stk, n_prims);
-            if (tv.cur == ND_DONE) {
+        const unsigned long long fin = __ballot(tv.done());              // finished or never started
+        if (PROF) { pf[0]++; pf[9] += 64 - __popcll(fin); }
+        if (fin && (__popcll(fin) >= thr.z || fin == ~0ull)) {
+            if (PROF) { pf[7]++; pf[8] += __popcll(__ballot(have && tv.done())); }
+            if (have && tv.done()) {
+                // retire: hand the result to the pool
                 if (ANY) {
                     float4 L = pool.li[slot];
                     unsigned int flags = __float_as_uint(L.w);
                     if (!tv.found) { float4 c = pool.sh_c[slot]; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
                     if (flags & PF_ENDING) {
                         float4 P = pool.pix[slot]; unsigned int pxy = __float_as_uint(P.z);
-                        if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), f3(L.x, L.y, L.z))) atomicAdd(&stats->invalid, 1ull);
+                        if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), f3(L.x, L.y, L.z))) n_invalid++;
                         L = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
                     }
                     pool.li[slot] = L;
@@ -345,18 +427,58 @@ __global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, flo
                 }
                 have = false;
             }
+            while (cursor >= end && !drained) {
+                const unsigned int s_lo = seg * seg_len, s_hi = (s_lo + seg_len < n) ? s_lo + seg_len : n;
+                unsigned int base = 0xffffffffu;
+                if (s_lo < n) { if (lane == 0) base = atomicAdd(&CN_HEAD(cnt, ANY, seg), ND_GRAB); base = __builtin_amdgcn_readfirstlane(base); }
+                if (s_lo < n && base < s_hi - s_lo) { cursor = s_lo + base; end = (cursor + ND_GRAB < s_hi) ? cursor + ND_GRAB : s_hi; seg_tried = 0; }
+                else { seg = (seg + 1) % ND_SEG; if (++seg_tried >= ND_SEG) drained = true; }
+            }
+            if (cursor < end) {
+                const unsigned int idx = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
+                if (tv.done() && idx < end) {
+                    slot = queue[idx];
+                    float4 ro = ANY ? pool.sh_o[slot] : pool.ray_o[slot], rd = ANY ? pool.sh_d[slot] : pool.ray_d[slot];
+                    Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
+                    if (!(r.maxt < r.mint)) n_rays++;
+                    have = true;
+                    tv.begin(sc, r, n_boxes);
+                }
+                cursor += (unsigned int) __popcll(fin);
+            }
+            if (drained && cursor >= end && __ballot(have) == 0ull) break;   // queue consumed and nothing in flight
         }
+        const unsigned long long m_in = __ballot(tv.at_inner());
+        bool ran = false;
+        if (m_in && (__popcll(m_in) >= thr.x || __ballot(tv.at_leaf()) == 0ull)) {
+            if (PROF) { pf[1]++; pf[2] += __popcll(m_in); }
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(sc, stk, n_boxes); }
+            else if (tv.at_inner()) tv.box_step(sc, stk, n_boxes);
+            ran = true;
+        }
+        const unsigned long long m_lf = __ballot(tv.at_leaf());
+        if (m_lf && (__popcll(m_lf) >= thr.y || !ran)) {
+            if (PROF) { pf[3]++; pf[4] += __popcll(m_lf); }
+            if (tv.at_leaf()) tv.prim_step(sc, n_prims);
+        }
+        if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
+        if (tv.at_pop()) tv.pop_step(stk);
     }
-    unsigned long long v[3] = {n_rays, n_boxes, n_prims};
-    for (int k = 0; k < 3; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
-    if (lane == 0 && (v[0] | v[1])) { atomicAdd(ANY ? &stats->shadow : &stats->closest, v[0]); atomicAdd(&stats->nodes, v[1]); atomicAdd(&stats->prims, v[2]); }
+    unsigned long long v[4] = {n_rays, n_boxes, n_prims, n_invalid};
+    for (int k = 0; k < 4; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
+    if (lane == 0 && (v[0] | v[1])) {
+        DevStats *st = my_stats(stats);
+        atomicAdd(ANY ? &st->shadow : &st->closest, v[0]); atomicAdd(&st->nodes, v[1]); atomicAdd(&st->prims, v[2]);
+        if (v[3]) atomicAdd(&st->invalid, v[3]);
+        if (PROF) for (int k = 0; k < 10; ++k) atomicAdd(&st->prof[ANY ? 1 : 0][k], (unsigned long long) pf[k]);
+    }
 }
 
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
 // stage launch per bounce would be mostly launch latency.  Each lane takes one surviving slot (its closest hit is
 // already in the pool) and runs its path to the end.
-__global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, unsigned int *n_ptr, DevStats *stats) {
-    const unsigned int n = *n_ptr;
+__global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, WfCounters *cnt, int cur, DevStats *stats) {
+    const unsigned int n = CN_ACTIVE(cnt, cur);
     ScratchStack stk; Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned int slot = queue[i];
@@ -391,9 +513,9 @@ __global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *
     unsigned long long v[5] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
     for (int k = 0; k < 5; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
     if ((threadIdx.x & 63) == 0 && (v[0] | v[1] | v[2])) {
-        atomicAdd(&stats->closest, v[0]); atomicAdd(&stats->shadow, v[1]); atomicAdd(&stats->invalid, v[2]); atomicAdd(&stats->nodes, v[3]); atomicAdd(&stats->prims, v[4]);
+        DevStats *st = my_stats(stats);
+        atomicAdd(&st->closest, v[0]); atomicAdd(&st->shadow, v[1]); atomicAdd(&st->invalid, v[2]); atomicAdd(&st->nodes, v[3]); atomicAdd(&st->prims, v[4]);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { }    // n_ptr is cleared by the host-side memset that follows this launch
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -480,11 +602,15 @@ struct NoriHipContext {
     int n_cus = 256;
     // wavefront pipeline
     unsigned int pool_slots = 0; Pool pool; void *pool_mem = nullptr;
-    unsigned int *d_queue[2] = {nullptr, nullptr}, *d_qshadow = nullptr; WfCounters *d_cnt = nullptr;
+    unsigned int *d_queue[2] = {nullptr, nullptr}, *d_qshadow = nullptr, *d_flags = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
     bool lds_stack = true;            // traversal stack of the trace stages: LDS (+ scratch spill) or scratch only
     unsigned int finish_below = 32768;
+    int shade_blocks_per_cu = 6;      // k_shade: blocks per CU (each block owns one contiguous run of the queue)
+    int trace_blocks_per_cu = 6;      // persistent trace waves: resident blocks per CU (LDS stack: 24.5 KB per block)
+    bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
+    int thr_box = 24, thr_prim = 16, thr_refill = 16;   // k_trace_queue step thresholds (lanes)
     void free_scene() {
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
@@ -512,12 +638,18 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipMalloc((void **) &c->d_counter, sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void **) &c->d_stats, sizeof(DevStats)));
-    HIPCHK(hipMemset(c->d_stats, 0, sizeof(DevStats)));
+    HIPCHK(hipMalloc((void **) &c->d_stats, ND_STRIPES * sizeof(DevStats)));
+    HIPCHK(hipMemset(c->d_stats, 0, ND_STRIPES * sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) c->pipeline = (std::string(e) == "mega") ? 0 : 1;
     if (const char *e = getenv("NORI_HIP_STACK")) c->lds_stack = std::string(e) != "scratch";
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
+    if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
+    if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->trace_blocks_per_cu = v; }
+    if (const char *e = getenv("NORI_HIP_PROFILE")) c->profile = atoi(e) != 0;
+    if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
+        int a, b, d; if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 1 && b >= 1 && d >= 1 && a <= 64 && b <= 64 && d <= 64) { c->thr_box = a; c->thr_prim = b; c->thr_refill = d; }
+    }
     c->pool_slots = 1u << 20;
     if (const char *e = getenv("NORI_HIP_POOL")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) c->pool_slots = (unsigned int) v; }
     HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
@@ -533,7 +665,7 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
     hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
-    hipFree(ctx->d_queue[0]); hipFree(ctx->d_queue[1]); hipFree(ctx->d_qshadow);
+    hipFree(ctx->d_queue[0]); hipFree(ctx->d_queue[1]); hipFree(ctx->d_qshadow); hipFree(ctx->d_flags);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
@@ -699,35 +831,38 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         Pool &pl = ctx->pool;
         pl.ray_o = base; pl.ray_d = base + P; pl.hit = (uint4 *) (base + 2 * P); pl.thr = base + 3 * P; pl.li = base + 4 * P;
         pl.rng = (uint4 *) (base + 5 * P); pl.pix = base + 6 * P; pl.sh_o = base + 7 * P; pl.sh_d = base + 8 * P; pl.sh_c = base + 9 * P;
-        HIPCHK(hipMalloc((void **) &ctx->d_queue[0], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_queue[1], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_qshadow, P * 4));
+        HIPCHK(hipMalloc((void **) &ctx->d_queue[0], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_queue[1], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_qshadow, P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_flags, P * 4));
     }
     unsigned int P = ctx->pool_slots;
     if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, ctx->d_queue[0], P, ctx->d_cnt);
     const bool lds = ctx->lds_stack;
+    const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
     const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below, P);
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     int cur = 0; uint64_t it = 0;
     for (;; ++it) {
         WfCounters *c = ctx->d_cnt;
         // grids sized by the (stale, hence conservative) live count: up to two rounds of resident waves
-        const unsigned trace_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 16u));
-        const unsigned shade_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 16u));
-        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c, cur);
+        const unsigned trace_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->trace_blocks_per_cu));
+        const unsigned shade_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
+        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, ctx->stream, c, cur);
         hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, job, ctx->d_film, (const unsigned int *) ctx->d_queue[cur],
-                           (const unsigned int *) &c->n_active[cur], ctx->d_queue[1 - cur], &c->n_active[1 - cur], ctx->d_qshadow, &c->n_shadow, ctx->d_counter, ctx->d_stats);
-        if (lds) {
-            hipLaunchKernelGGL((k_trace_queue<true, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qshadow, (const unsigned int *) &c->n_shadow, ctx->d_stats);
-            hipLaunchKernelGGL((k_trace_queue<false, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_queue[1 - cur], (const unsigned int *) &c->n_active[1 - cur], ctx->d_stats);
-        } else {
-            hipLaunchKernelGGL((k_trace_queue<true, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qshadow, (const unsigned int *) &c->n_shadow, ctx->d_stats);
-            hipLaunchKernelGGL((k_trace_queue<false, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_queue[1 - cur], (const unsigned int *) &c->n_active[1 - cur], ctx->d_stats);
+                           ctx->d_queue[1 - cur], ctx->d_qshadow, ctx->d_flags, c, cur, ctx->d_counter, ctx->d_stats);
+        {
+            const unsigned int *qs = ctx->d_qshadow, *qe = ctx->d_queue[1 - cur];
+#define ND_LAUNCH_TRACE(L, PR) \
+            hipLaunchKernelGGL((k_trace_queue<true, L, PR>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, qs, c, 1 - cur, ctx->d_stats, thr); \
+            hipLaunchKernelGGL((k_trace_queue<false, L, PR>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, qe, c, 1 - cur, ctx->d_stats, thr);
+            if (ctx->profile) { if (lds) { ND_LAUNCH_TRACE(true, true) } else { ND_LAUNCH_TRACE(false, true) } }
+            else { if (lds) { ND_LAUNCH_TRACE(true, false) } else { ND_LAUNCH_TRACE(false, false) } }
+#undef ND_LAUNCH_TRACE
         }
         HIPCHK(hipGetLastError());
         // the live count comes back through a 4-deep ring of pinned words, so the host runs at most three iterations
         // ahead of the device and never waits on the iteration it has just queued
-        HIPCHK(hipMemcpyAsync(&ctx->h_ring[it & 3], &c->n_active[1 - cur], sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&ctx->h_ring[it & 3], &CN_ACTIVE(c, 1 - cur), sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ring_ev[it & 3], ctx->stream));
         cur = 1 - cur;
         if (it >= 3) {
@@ -737,7 +872,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
                 hipLaunchKernelGGL(k_finish, dim3(std::max(1u, (n_upper + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film,
-                                   (const unsigned int *) ctx->d_queue[cur], &c->n_active[cur], ctx->d_stats);
+                                   (const unsigned int *) ctx->d_queue[cur], c, cur, ctx->d_stats);
                 HIPCHK(hipGetLastError());
                 ++it;
                 break;
@@ -821,17 +956,31 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     CTXCHK(ctx);
     if (!out) return fail(NORI_HIP_EINVAL, "null buffer");
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    DevStats ds; HIPCHK(hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
+    std::vector<DevStats> stripes(ND_STRIPES);
+    HIPCHK(hipMemcpy(stripes.data(), ctx->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
+    DevStats ds; std::memset(&ds, 0, sizeof(ds));
+    for (const DevStats &t : stripes) {
+        ds.samples += t.samples; ds.closest += t.closest; ds.shadow += t.shadow; ds.invalid += t.invalid; ds.nodes += t.nodes; ds.prims += t.prims;
+        for (int k = 0; k < 2; ++k) for (int j = 0; j < 10; ++j) ds.prof[k][j] += t.prof[k][j];
+    }
     ctx->stats.camera_samples = ds.samples; ctx->stats.closest_rays = ds.closest; ctx->stats.shadow_rays = ds.shadow; ctx->stats.invalid_samples = ds.invalid;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->stats.render_ms = ms; else (void) hipGetLastError();
     ctx->stats.boxes_tested = ds.nodes; ctx->stats.prims_tested = ds.prims;
+    if (ctx->profile) {
+        static const char *names[10] = {"trips", "box_runs", "box_lanes", "prim_runs", "prim_lanes", "pop_runs", "pop_lanes", "refill_runs", "retired", "busy_lanes"};
+        for (int k = 0; k < 2; ++k) {
+            fprintf(stderr, "[nori_hip profile] %s:", k ? "shadow" : "extend");
+            for (int j = 0; j < 10; ++j) fprintf(stderr, " %s=%llu", names[j], ds.prof[k][j]);
+            fprintf(stderr, "\n");
+        }
+    }
     *out = ctx->stats;
     return NORI_HIP_OK;
 }
 int nori_hip_reset_stats(NoriHipContext *ctx) {
     CTXCHK(ctx);
-    HIPCHK(hipMemsetAsync(ctx->d_stats, 0, sizeof(DevStats), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_stats, 0, ND_STRIPES * sizeof(DevStats), ctx->stream));
     return NORI_HIP_OK;
 }
 int nori_hip_stream(NoriHipContext *ctx, void **stream) { CTXCHK(ctx); if (stream) *stream = ctx->stream; return NORI_HIP_OK; }

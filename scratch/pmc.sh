@@ -15,13 +15,4 @@ TCC_HIT TCC_MISS TCC_READ TCC_WRITE
 FETCH_SIZE
 WRITE_SIZE
 PASSES
-python3 - <<PY
-import csv, glob, collections
-tot = collections.defaultdict(float)
-for f in sorted(glob.glob('gpurun_out/pmc_${tag}_*/*/*counter_collection.csv')):
-    for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name']
-        name = 'k_render' if 'k_render' in k else ('k_shade' if 'k_shade' in k else ('shadow' if 'k_trace_queue<true' in k else ('extend' if 'k_trace_queue<false' in k else ('finish' if 'k_finish' in k else None))))
-        if name: tot[(name, r['Counter_Name'])] += float(r['Counter_Value'])
-for k in sorted(tot): print(k[0], k[1], '%.6g' % tot[k])
-PY
+python3 scratch/pmc_sum.py $tag
