@@ -91,6 +91,8 @@ struct DevScene {
     const float *cdf;
     const NoriHipShadePrim *light_prims;
     uint32_t root, n_emitters;
+    int prim_lanes;                    // run-to-completion traversal: lanes that must wait at a leaf before a record step is issued
+    uint32_t n_top;                    // nodes [0, n_top) are the top of the tree in breadth-first order (LDS cache candidates)
     float root_min[3], root_max[3];
     NoriHipCamera cam;
     float inv_w, inv_h;
@@ -120,6 +122,33 @@ __device__ __forceinline__ bool slab(const float *bmin, const float *bmax, F3 o,
     near_out = nearT;
     return ok & (mint <= farT) & (nearT <= maxt);
 }
+
+// Where box steps fetch their 64-byte node from.  GlobalNodes: always HBM/L2 through the vector memory path.
+// CachedNodes: the first `n` nodes (the top of the tree, breadth-first, see nori_hip_upload_scene) live in the
+// workgroup's LDS, whose random-access rate and latency are several times better than the L1/TA path's; deeper
+// nodes still come from memory.
+typedef float nd_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) nd_v4f lds_f4;
+__device__ __forceinline__ float4 nd_f4(nd_v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
+struct GlobalNodes {
+    const NoriHipNode *nodes;
+    __device__ __forceinline__ void fetch(uint32_t cur, float4 &n0, float4 &n1, float4 &n2, float4 &n3) const {
+        const float4 *q = reinterpret_cast<const float4 *>(nodes + cur);
+        n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+    }
+};
+struct CachedNodes {
+    const NoriHipNode *nodes; lds_f4 *cache; uint32_t n;
+    __device__ __forceinline__ void fetch(uint32_t cur, float4 &n0, float4 &n1, float4 &n2, float4 &n3) const {
+        if (cur < n) { const lds_f4 *q = cache + 4 * cur; n0 = nd_f4(q[0]); n1 = nd_f4(q[1]); n2 = nd_f4(q[2]); n3 = nd_f4(q[3]); }
+        else { const float4 *q = reinterpret_cast<const float4 *>(nodes + cur); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+    }
+    // cooperative fill by the whole workgroup; the caller synchronises afterwards
+    __device__ __forceinline__ void fill() const {
+        const float4 *g = reinterpret_cast<const float4 *>(nodes);
+        for (uint32_t i = threadIdx.x; i < 4 * n; i += blockDim.x) { float4 v = g[i]; nd_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; cache[i] = w; }
+    }
+};
 
 #ifndef ND_STACK
 #define ND_STACK 64        /* the reference's traversal stack holds 64 entries (src/bvh.cpp:405) */
@@ -176,9 +205,8 @@ template <bool ANY> struct Trav {
     // bbox.h:345-358) return exactly min/max of their operands; its per-axis "nearT > farT" exits are implied by the
     // final comparison because nearT only grows and farT only shrinks.  Same decisions and entry distances (up to
     // the sign of a zero, which no comparison sees), a third of the instructions.
-    template <typename StackT> __device__ __forceinline__ void box_step_fast(const DevScene &sc, StackT &stk, uint32_t &n_boxes) {
-        const float4 *q = reinterpret_cast<const float4 *>(sc.nodes + cur);
-        float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+    template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step_fast(const NodesT &nodes, StackT &stk, uint32_t &n_boxes) {
+        float4 n0, n1, n2, n3; nodes.fetch(cur, n0, n1, n2, n3);
         uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
         n_boxes += 2;
         float ax1 = (n0.x - o.x) * rcp.x, ax2 = (n0.w - o.x) * rcp.x;
@@ -196,9 +224,8 @@ template <bool ANY> struct Trav {
         if (hl & hr) stk.push(sp++, make_uint2(right, __float_as_uint(nrr)));
         cur = hl ? left : (hr ? right : ND_POP);
     }
-    template <typename StackT> __device__ __forceinline__ void box_step(const DevScene &sc, StackT &stk, uint32_t &n_boxes) {
-        const float4 *q = reinterpret_cast<const float4 *>(sc.nodes + cur);
-        float4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
+    template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step(const NodesT &nodes, StackT &stk, uint32_t &n_boxes) {
+        float4 n0, n1, n2, n3; nodes.fetch(cur, n0, n1, n2, n3);
         float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
         float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
         uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
@@ -260,18 +287,32 @@ template <bool ANY> struct Trav {
 };
 
 // run one ray to completion
-template <bool ANY, typename StackT>
-__device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
+// Run one ray per lane to completion.  Every trip serves the lanes at an inner node, then the lanes at a leaf
+// record once at least sc.prim_lanes of them have gathered (or no lane is at an inner node), then the pops.  A lane
+// that waits at a leaf costs nothing; per lane the sequence of steps is the same as in a private loop.
+template <bool ANY, typename StackT, typename NodesT>
+__device__ __forceinline__ bool trace(const DevScene &sc, const NodesT &nodes, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
     Trav<ANY> tv;
-    if (tv.begin(sc, ray_in, n_nodes)) {
-        while (!tv.done()) {
-            if (tv.at_inner()) { if (tv.special) tv.box_step(sc, stk, n_nodes); else tv.box_step_fast(sc, stk, n_nodes); }
-            if (tv.at_leaf()) tv.prim_step(sc, n_prims);
-            if (tv.at_pop()) tv.pop_step(stk);
+    tv.begin(sc, ray_in, n_nodes);
+    for (;;) {
+        const unsigned long long m_in = __ballot(tv.at_inner());
+        if (m_in) {
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, n_nodes); }
+            else if (tv.at_inner()) { if (tv.special) tv.box_step(nodes, stk, n_nodes); else tv.box_step_fast(nodes, stk, n_nodes); }
         }
+        const unsigned long long m_lf = __ballot(tv.at_leaf());
+        if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) { if (tv.at_leaf()) tv.prim_step(sc, n_prims); }
+        if (tv.at_pop()) tv.pop_step(stk);
+        if (__ballot(!tv.done()) == 0ull) break;
     }
     hit = tv.hit;
     return tv.found;
+}
+
+template <bool ANY, typename StackT>
+__device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
+    GlobalNodes g; g.nodes = sc.nodes;
+    return trace<ANY>(sc, g, ray_in, hit, stk, n_nodes, n_prims);
 }
 
 // per-lane stack in private (scratch) memory
@@ -280,6 +321,21 @@ struct ScratchStack {
     __device__ __forceinline__ void push(int i, uint2 v) { e[i] = v; }
     __device__ __forceinline__ uint2 pop(int i) const { return e[i]; }
 };
+
+// Per-lane traversal stack with its first LDS_DEPTH entries in LDS ([entry][lane] layout: the 64 lanes of a wave
+// touch 64 consecutive 8-byte words, conflict-free for ds_read/write_b64) and the rare deeper entries in scratch.
+#define LDS_DEPTH 12
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+template <int DEPTH> struct LdsStackT {
+    lds_u64 *base;                      // this lane's column: base[entry * 64] (LDS address space, so ds_read/ds_write)
+    uint2 spill[ND_STACK - DEPTH];
+    __device__ __forceinline__ void push(int i, uint2 v) { if (i < DEPTH) base[i * 64] = ((unsigned long long) v.y << 32) | v.x; else spill[i - DEPTH] = v; }
+    __device__ __forceinline__ uint2 pop(int i) const {
+        if (i < DEPTH) { unsigned long long w = base[i * 64]; return make_uint2((unsigned int) w, (unsigned int) (w >> 32)); }
+        return spill[i - DEPTH];
+    }
+};
+typedef LdsStackT<LDS_DEPTH> LdsStack;
 
 struct Surface { F3 p; F2 uv; Frame sh; F3 geo_n; uint32_t shape; uint32_t prim; };
 
@@ -580,19 +636,24 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
 }
 
 // One iteration of the reference's bounce loop, run to completion by one lane.  Returns false when the path ended.
-template <typename StackT>
-__device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
+template <typename StackT, typename NodesT>
+__device__ __forceinline__ bool path_bounce(const DevScene &sc, const NodesT &nodes, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     Hit hit;
     ctr.closest++;
-    if (!trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+    if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
     ShadeOut so;
     shade_hit(sc, ps, rng, hit, so);
     if (so.has_shadow) {
         Hit sh_hit;
         ctr.shadow++;
-        if (!trace<true>(sc, so.shadow, sh_hit, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
+        if (!trace<true>(sc, nodes, so.shadow, sh_hit, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
     }
     return !so.end;
+}
+template <typename StackT>
+__device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
+    GlobalNodes g; g.nodes = sc.nodes;
+    return path_bounce(sc, g, ps, rng, stk, ctr);
 }
 
 } // namespace nd

@@ -127,8 +127,18 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
 // Work items are handed out ND_WORK_GRAB at a time per wave (one atomic by one lane) and dealt to the lanes whose
 // path has ended with a ballot + prefix count, so the global counter sees one atomic per ND_WORK_GRAB samples.
 #define ND_WORK_GRAB 256u
-__global__ __launch_bounds__(256) void k_render(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats) {
-    ScratchStack stk;
+// Workgroups of 256 lanes; LDS holds the traversal stacks (MEGA_DEPTH entries per lane) and, in the rest of the
+// workgroup's share, the top `n_cached` nodes of the tree.  The kernel is latency-bound (a dependent node or record
+// fetch per trip), so it is built for several register budgets (waves per SIMD) and the host picks one.
+#define MEGA_THREADS 256
+#define MEGA_DEPTH 8
+__device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob &job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
+    extern __shared__ float4 dyn_lds[];
+    LdsStackT<MEGA_DEPTH> stk; stk.base = (lds_u64 *) dyn_lds + (threadIdx.x >> 6) * (MEGA_DEPTH * 64) + (threadIdx.x & 63u);
+    CachedNodes nodes; nodes.nodes = sc.nodes; nodes.n = n_cached;
+    nodes.cache = (lds_f4 *) dyn_lds + (MEGA_THREADS / 64) * (MEGA_DEPTH * 64 * 8 / 16);
+    nodes.fill();
+    __syncthreads();
     Counters ctr = {0, 0, 0, 0};
     unsigned int n_samples = 0, n_invalid = 0;
     PathState ps; Pcg32 rng; F2 pixel_sample = f2(0.f, 0.f); int px = 0, py = 0;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256) void k_render(DevScene sc, RenderJob job, floa
         }
         if (__ballot(alive) == 0ull) { if (exhausted && cursor >= end) break; else continue; }
         if (alive) {
-            if (!path_bounce(sc, ps, rng, stk, ctr)) {
+            if (!path_bounce(sc, nodes, ps, rng, stk, ctr)) {
                 if (!film_put(sc, film, pixel_sample, px, py, ps.li)) n_invalid++;
                 alive = false;
             }
@@ -186,85 +196,98 @@ __global__ __launch_bounds__(256) void k_render(DevScene sc, RenderJob job, floa
         atomicAdd(&st->invalid, v[3]); atomicAdd(&st->nodes, v[4]); atomicAdd(&st->prims, v[5]);
     }
 }
+#define ND_RENDER_KERNEL(W) \
+__global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(W, W))) \
+void k_render_w##W(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) { \
+    render_body(sc, job, film, work_counter, stats, n_cached); }
+ND_RENDER_KERNEL(3)
+ND_RENDER_KERNEL(4)
+ND_RENDER_KERNEL(5)
+ND_RENDER_KERNEL(6)
+ND_RENDER_KERNEL(8)
 
 // ---------------------------------------------------------------------------------------------------------
 // Wavefront pipeline: the bounce loop of PathMisIntegrator::Li cut into stages that run as separate kernels over
-// a pool of path slots (struct-of-arrays in HBM), so that each kernel keeps few registers live and every lane of
-// a wave does the same kind of work:
-//   k_shade        shades the hits of the previous extend (emission+MIS, roulette, BSDF sample, emitter sample),
-//                  splats finished paths and regenerates their slots from the global work counter, queues the
-//                  shadow rays and the slots that go on
-//   k_trace_queue  <ANY=true>  shadow stage: any-hit for the queued shadow rays, adds the NEE term when unoccluded
-//                  <ANY=false> extend stage: closest hit for every live slot
-// Both trace stages are persistent waves that pull rays from their queue through one atomic head counter and refill
-// a lane as soon as its ray has finished (while-while traversal with dynamic fetch), so lanes do not idle behind
-// the longest traversal of their wave.
-enum { PF_LAST_DELTA = 1u, PF_ENDING = 2u, PF_ACTIVE = 4u };
+// a pool of path slots (struct-of-arrays in HBM, indexed by slot), so that each kernel keeps few registers live and
+// every lane of a wave does the same kind of work.  One iteration = one bounce of every live path:
+//   k_shade               adds the NEE term whose shadow ray the previous iteration traced, shades the new hits
+//                         (emission+MIS, roulette, BSDF sample, emitter sample), splats finished paths and starts
+//                         new ones in their slots from the global work counter; leaves the next ray and the
+//                         shadow ray of every slot in the pool (or a marker maxt < mint for "none")
+//   k_trace_pool<ANY>     shadow stage: any-hit for the shadow rays, writes one visibility word per slot
+//   k_trace_pool<!ANY>    extend stage: closest hit for the next rays, writes the hit record per slot
+// All three walk the pool in slot order, so their HBM accesses are coalesced, and nothing but the work counter,
+// the live count and the statistics is shared between waves.
+enum { PF_LAST_DELTA = 1u, PF_ENDING = 2u, PF_ACTIVE = 4u, PF_SHADOW = 8u };
 
 struct Pool {
     float4 *ray_o;     // o.xyz, mint
-    float4 *ray_d;     // d.xyz, maxt
+    float4 *ray_d;     // d.xyz, maxt                (maxt < mint: no ray)
     uint4  *hit;       // record index (0xffffffff = miss), t, u, v
     float4 *thr;       // throughput rgb, pdf of the last BSDF sample
     float4 *li;        // radiance so far rgb, flags (PF_*)
     uint4  *rng;       // pcg32 state, inc
     float4 *pix;       // pixel sample x, y, integer pixel (x | y << 16), unused
     float4 *sh_o;      // shadow ray o.xyz, mint
-    float4 *sh_d;      // shadow ray d.xyz, maxt
-    float4 *sh_c;      // NEE contribution rgb if unoccluded
+    float4 *sh_d;      // shadow ray d.xyz, maxt     (maxt < mint: no ray)
+    float4 *sh_c;      // NEE contribution rgb if unoccluded; w: set to 1 by the shadow stage when unoccluded
 };
 
-// Queue counters, one per 256-byte line (see DevStats): the two live-slot counts, the shadow count, and the heads
-// of the trace stages, which are striped: a queue of n entries is cut into ND_SEG equal segments with a head each,
-// a wave starts at segment (wave % ND_SEG) and moves on to the next one when its segment is used up.
-#define ND_SEG 32
+// Counters, one per 256-byte line (see DevStats).  v[0]: slots that hold a live path after the last shade stage.
 #define ND_LINE 64                              /* unsigned ints per 256-byte line */
-struct WfCounters { unsigned int v[(3 + 2 * ND_SEG) * ND_LINE]; };
-#define CN_ACTIVE(c, i)  ((c)->v[(i) * ND_LINE])
-#define CN_SHADOW(c)     ((c)->v[2 * ND_LINE])
-#define CN_HEAD(c, any, k) ((c)->v[(3 + ((any) ? ND_SEG : 0) + (k)) * ND_LINE])
+struct WfCounters { unsigned int v[2 * ND_LINE]; };
+#define CN_LIVE(c) ((c)->v[0])
 
-__global__ void k_pool_init(Pool pool, unsigned int *queue, unsigned int n, WfCounters *cnt) {
+__global__ void k_pool_init(Pool pool, unsigned int n, WfCounters *cnt) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { queue[i] = i; pool.li[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u)); }
-    if (i < 3 + 2 * ND_SEG) cnt->v[i * ND_LINE] = (i == 0) ? n : 0u;
+    if (i < n) {
+        pool.li[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+        pool.ray_d[i] = make_float4(0.f, 0.f, 0.f, -1.f); pool.ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pool.sh_d[i] = make_float4(0.f, 0.f, 0.f, -1.f); pool.sh_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (i == 0) CN_LIVE(cnt) = 0u;
 }
-__global__ void k_iter_begin(WfCounters *cnt, int cur) {
-    unsigned int i = threadIdx.x;
-    if (i < 3 + 2 * ND_SEG && i != (unsigned int) cur) cnt->v[i * ND_LINE] = 0u;       // everything except the input count
+__global__ void k_iter_begin(WfCounters *cnt) { CN_LIVE(cnt) = 0u; }
+
+// What k_shade and k_finish do with a slot before its new hit is looked at: add the NEE term of the previous bounce
+// if its shadow ray was unoccluded (src/pathMisIntegrator.cpp:150-163; the sum order of Li is the reference's: the
+// NEE term of bounce k enters before the emission term of bounce k+1).
+__device__ __forceinline__ F3 add_pending_nee(F3 li, unsigned int flags, float4 c) {
+    if ((flags & PF_SHADOW) && c.w != 0.f) li = li + f3(c.x, c.y, c.z);
+    return li;
 }
 
-// Shade stage.  Each block owns a contiguous run of the input queue and walks it twice:
-//   pass A  shades the hits (emission+MIS, roulette, BSDF sample, emitter sample), splats finished paths, and leaves
-//           one flag word per queue position (regenerate / has a shadow ray / goes on)
-//   then ONE set of three atomics per block reserves the block's camera samples and its room in the two output
-//           queues (per-wave totals are combined through LDS)
-//   pass B  regenerates the freed slots from the reserved work items (src/render.cpp:83-98) and writes the queues
-enum { SF_REGEN = 1u, SF_SHADOW = 2u, SF_KEEP = 4u };
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, RenderJob job, float4 *film, const unsigned int *q_in, unsigned int *q_next, unsigned int *q_shadow,
-                                               unsigned int *flag_buf, WfCounters *cnt, int cur, unsigned long long *work_counter, DevStats *stats) {
-    __shared__ unsigned int w_tot[4][3];
-    __shared__ unsigned long long b_work; __shared__ unsigned int b_next, b_shadow;
-    const unsigned int n_in = CN_ACTIVE(cnt, cur);
+// Shade stage.  Each block owns a contiguous run of slots and walks it twice:
+//   pass A  shades (see above) and leaves one flag word per slot (regenerate / stays live)
+//   then ONE pair of atomics per block reserves the block's camera samples and its room in the live list
+//           (per-wave totals are combined through LDS)
+//   pass B  starts new paths in the freed slots from the reserved work items (src/render.cpp:83-98) and writes the
+//           live list (used by the host for termination and by k_finish)
+enum { SF_REGEN = 1u, SF_KEEP = 2u, SF_IDLE = 4u };
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
+                                               unsigned int *flag_buf, WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
+    __shared__ unsigned int w_tot[4][2];
+    __shared__ unsigned long long b_work; __shared__ unsigned int b_live;
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
     const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
-    const unsigned int per_block = (((n_in + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
-    const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_in) ? lo + per_block : n_in;
-    unsigned int c_regen = 0, c_shadow = 0, c_keep = 0, n_invalid = 0;      // the first three are wave-uniform
+    const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
+    const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
+    unsigned int c_regen = 0, c_keep = 0, n_invalid = 0;                    // the first two are wave-uniform
+    const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
     for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
-        const unsigned int i = i0 + lane;
+        const unsigned int slot = i0 + lane;
         unsigned int f = 0u;
-        if (i < hi) {
-            const unsigned int slot = q_in[i];
+        if (slot < hi) {
             const float4 L = pool.li[slot]; const uint4 h = pool.hit[slot]; const float4 P = pool.pix[slot];
             const float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; const uint4 R = pool.rng[slot];
+            const float4 C = pool.sh_c[slot];
             unsigned int flags = __float_as_uint(L.w);
-            f = SF_REGEN;
+            f = SF_REGEN | SF_IDLE;
             if (flags & PF_ACTIVE) {
-                PathState ps; ps.li = f3(L.x, L.y, L.z);
-                bool ended = true;
-                if (h.x != 0xffffffffu) {
+                PathState ps; ps.li = add_pending_nee(f3(L.x, L.y, L.z), flags, C);
+                bool ended = true, new_shadow = false;
+                if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
                     ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
                     ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
                     Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
@@ -273,61 +296,60 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, RenderJob
                     shade_hit(sc, ps, rng, hit, so);
                     flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
                     if (so.has_shadow) {
+                        new_shadow = true; flags |= PF_SHADOW;
                         pool.sh_o[slot] = make_float4(so.shadow.o.x, so.shadow.o.y, so.shadow.o.z, so.shadow.mint);
                         pool.sh_d[slot] = make_float4(so.shadow.d.x, so.shadow.d.y, so.shadow.d.z, so.shadow.maxt);
                         pool.sh_c[slot] = make_float4(so.contrib.x, so.contrib.y, so.contrib.z, 0.f);
-                        f = SF_SHADOW;
-                    } else f = 0u;
+                    }
                     if (!so.end) {
-                        ended = false; f |= SF_KEEP;
+                        ended = false; f = SF_KEEP;
                         pool.ray_o[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.mint);
                         pool.ray_d[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.ray.maxt);
                         pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
                         pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
                     } else if (so.has_shadow) {
-                        // the path ends, but its last NEE term is still pending: the shadow stage adds it, splats and frees the slot
-                        ended = false; f |= SF_KEEP;
-                        pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);          // maxt < mint: the extend stage skips it
+                        // the path ends, but its last NEE term is still pending: it stays one more iteration without a next ray
+                        ended = false; f = SF_KEEP;
+                        pool.ray_d[slot] = no_ray;
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags | PF_ENDING));
                     }
                 }
+                if (!new_shadow) pool.sh_d[slot] = no_ray;
                 if (ended) {
                     unsigned int pxy = __float_as_uint(P.z);
                     if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
                     f = SF_REGEN;
                 }
             }
-            flag_buf[i] = f;
+            flag_buf[slot] = f;
         }
         c_regen += (unsigned int) __popcll(__ballot((f & SF_REGEN) != 0u));
-        c_shadow += (unsigned int) __popcll(__ballot((f & SF_SHADOW) != 0u));
         c_keep += (unsigned int) __popcll(__ballot((f & SF_KEEP) != 0u));
     }
-    if (lane == 0) { w_tot[wv][0] = c_regen; w_tot[wv][1] = c_shadow; w_tot[wv][2] = c_keep; }
+    if (lane == 0) { w_tot[wv][0] = c_regen; w_tot[wv][1] = c_keep; }
     __syncthreads();
-    unsigned int t_regen = 0, t_shadow = 0, t_keep = 0, o_regen = 0, o_shadow = 0, o_keep = 0;
+    unsigned int t_regen = 0, t_keep = 0, o_regen = 0, o_keep = 0;
     for (unsigned int k = 0; k < 4; ++k) {
-        if (k == wv) { o_regen = t_regen; o_shadow = t_shadow; o_keep = t_keep; }
-        t_regen += w_tot[k][0]; t_shadow += w_tot[k][1]; t_keep += w_tot[k][2];
+        if (k == wv) { o_regen = t_regen; o_keep = t_keep; }
+        t_regen += w_tot[k][0]; t_keep += w_tot[k][1];
     }
     if (threadIdx.x == 0) {
-        unsigned long long bw = t_regen ? atomicAdd(work_counter, (unsigned long long) t_regen) : padded_total;
+        // (a plain load first: once the work has run out, the blocks stop bumping the counter)
+        unsigned long long bw = padded_total;
+        if (t_regen && *(volatile unsigned long long *) work_counter < padded_total) bw = atomicAdd(work_counter, (unsigned long long) t_regen);
         unsigned int n_valid = (bw >= padded_total) ? 0u : (unsigned int) ((padded_total - bw < (unsigned long long) t_regen) ? padded_total - bw : (unsigned long long) t_regen);
         b_work = bw;
-        b_next = (t_keep + n_valid) ? atomicAdd(&CN_ACTIVE(cnt, 1 - cur), t_keep + n_valid) : 0u;
-        b_shadow = t_shadow ? atomicAdd(&CN_SHADOW(cnt), t_shadow) : 0u;
+        b_live = (t_keep + n_valid) ? atomicAdd(&CN_LIVE(cnt), t_keep + n_valid) : 0u;
     }
     __syncthreads();
-    const unsigned long long base_w = b_work; const unsigned int base_n = b_next, base_s = b_shadow;
+    const unsigned long long base_w = b_work; const unsigned int base_n = b_live;
     unsigned int n_samples = 0;
     for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
-        const unsigned int i = i0 + lane;
-        unsigned int f = 0u, slot = 0u;
-        if (i < hi) { f = flag_buf[i]; slot = q_in[i]; }
-        const unsigned long long m_r = __ballot((f & SF_REGEN) != 0u), m_s = __ballot((f & SF_SHADOW) != 0u), m_k = __ballot((f & SF_KEEP) != 0u);
-        if (f & SF_SHADOW) q_shadow[base_s + o_shadow + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_s >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_s, 0u))] = slot;
-        if (f & SF_KEEP) q_next[base_n + o_keep + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_k, 0u))] = slot;
+        const unsigned int slot = i0 + lane;
+        const unsigned int f = (slot < hi) ? flag_buf[slot] : 0u;
+        const unsigned long long m_r = __ballot((f & SF_REGEN) != 0u), m_k = __ballot((f & SF_KEEP) != 0u);
+        if (f & SF_KEEP) q_live[base_n + o_keep + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_k, 0u))] = slot;
         if (f & SF_REGEN) {
             const unsigned int r = o_regen + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_r >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_r, 0u));
             const unsigned long long w = base_w + r;
@@ -347,113 +369,101 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, RenderJob
                     pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(PF_ACTIVE | PF_LAST_DELTA));
                     n_samples++;
                 } else {
-                    // padding of an edge patch: the slot stays in the queue, idle, and draws again in the next iteration
-                    pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);
+                    // padding of an edge patch: the slot counts as live, idle, and draws again in the next iteration
+                    pool.ray_d[slot] = no_ray;
                     pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
                 }
-                q_next[base_n + t_keep + (unsigned int) (w - base_w)] = slot;
-            } else {
-                pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));      // no work left: the slot retires
+                q_live[base_n + t_keep + (unsigned int) (w - base_w)] = slot;
+            } else if (!(f & SF_IDLE)) {
+                pool.ray_d[slot] = no_ray;                                            // no work left: the slot retires
+                pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
             }
         }
-        o_regen += (unsigned int) __popcll(m_r); o_shadow += (unsigned int) __popcll(m_s); o_keep += (unsigned int) __popcll(m_k);
+        o_regen += (unsigned int) __popcll(m_r); o_keep += (unsigned int) __popcll(m_k);
     }
     unsigned long long v0 = n_samples, v1 = n_invalid;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
     if (lane == 0 && (v0 | v1)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); }
 }
 
-// Per-lane traversal stack with its first LDS_DEPTH entries in LDS ([entry][lane] layout: the 64 lanes of a wave
-// touch 64 consecutive 8-byte words, conflict-free for ds_read/write_b64) and the rare deeper entries in scratch.
-#define LDS_DEPTH 12
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-struct LdsStack {
-    lds_u64 *base;                      // this lane's column: base[entry * 64] (LDS address space, so ds_read/ds_write)
-    uint2 spill[ND_STACK - LDS_DEPTH];
-    __device__ __forceinline__ void push(int i, uint2 v) { if (i < LDS_DEPTH) base[i * 64] = ((unsigned long long) v.y << 32) | v.x; else spill[i - LDS_DEPTH] = v; }
-    __device__ __forceinline__ uint2 pop(int i) const {
-        if (i < LDS_DEPTH) { unsigned long long w = base[i * 64]; return make_uint2((unsigned int) w, (unsigned int) (w >> 32)); }
-        return spill[i - LDS_DEPTH];
-    }
-};
-
-// Trace stage: persistent waves.  A wave takes ND_GRAB consecutive queue entries at a time from the head of its
-// current queue segment (one atomic per grab, issued by one lane) and hands them to whichever lanes are free
-// (ballot + prefix count), so lanes are refilled while their neighbours keep traversing and waves only run dry
-// when the whole queue has been handed out.
+// Trace stage: persistent waves over the pool.  Wave w of W takes the 64-slot batches w, w+W, w+2W, ... (a static,
+// interleaved share: no shared counter).  Rays reach the lanes through a small pipeline, so that the HBM latency of
+// the pool is paid once per batch and overlaps with traversal instead of stalling every trip:
+//   load     one batch ahead, coalesced, into registers (the wait lands one or more trips later)
+//   stage    the rays that exist (maxt >= mint) are packed into the wave's LDS buffer
+//   hand out a lane whose ray has finished takes the next staged ray (ballot + prefix count)
 // Every trip of the loop the wave decides, from ballots of the lane states, which traversal step is worth issuing:
 //   retire+refill  when at least `thr.z` lanes have finished (or nothing else is left to do)
 //   box_step       when at least `thr.x` lanes stand at an inner node (or no lane stands at a leaf)
 //   prim_step      when at least `thr.y` lanes stand at a leaf record (or the box step did not run)
 //   pop_step       for the lanes that need a stack entry
-// The steps are straight-line code, so the lanes that take part in a step all do useful work; a lane in the
-// minority state waits a few trips until its kind of step is issued.  At least one step runs per trip, so the loop
-// always makes progress and ends when the queue is consumed and every lane has retired its ray.
-#define ND_GRAB 64u
-template <bool ANY, bool USE_LDS, bool PROF>
-__global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, WfCounters *cnt, int cur, DevStats *stats, int3 thr) {
-    __shared__ uint2 lds_stack[USE_LDS ? 4 * LDS_DEPTH * 64 : 1];
-    const unsigned int n = ANY ? CN_SHADOW(cnt) : CN_ACTIVE(cnt, cur);
-    const unsigned int lane = threadIdx.x & 63u;
-    const unsigned int seg_len = (((n + ND_SEG - 1) / ND_SEG) + 63u) & ~63u;          // entries per segment (the last ones may be short or empty)
-    unsigned int seg = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) % ND_SEG, seg_tried = 0;   // wave-uniform
-    unsigned int cursor = 0, end = 0;                                    // wave-uniform: the entries [cursor, end) are ours
-    bool drained = (n == 0);                                             // wave-uniform: every segment has been handed out
-    typename std::conditional<USE_LDS, LdsStack, ScratchStack>::type stk;
-    if constexpr (USE_LDS) stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
+// The steps are straight-line code.  At least one step runs per trip, so the loop always makes progress; it ends
+// when the wave's batches are used up and every lane has retired its ray.  Results leave through plain stores:
+// the hit record (extend) or the visibility word sh_c.w (shadow).
+template <bool ANY, bool PROF>
+__global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr) {
+    __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
+    __shared__ float4 st_o[4][64], st_d[4][64];
+    __shared__ unsigned int st_slot[4][64];
+    const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, n_batches = (n_slots + 63u) >> 6;
+    unsigned int b_next = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform: next batch to load
+    bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
+    float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
+    unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
+    LdsStack stk; stk.base = (lds_u64 *) lds_stack + wv * (LDS_DEPTH * 64) + lane;
+    GlobalNodes nodes; nodes.nodes = sc.nodes;
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
     bool have = false; unsigned int slot = 0;
-    uint32_t n_boxes = 0, n_prims = 0, n_rays = 0, n_invalid = 0;
+    uint32_t n_boxes = 0, n_prims = 0, n_rays = 0;
     unsigned int pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // PROF only: wave-uniform step statistics
     for (;;) {
+        // ---- feed the staging pipeline
+        if (s_pos >= s_n && loading) {
+            const bool valid = !(ld4.w < lo4.w);
+            const unsigned long long m = __ballot(valid);
+            if (valid) {
+                const unsigned int r = __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
+                st_o[wv][r] = lo4; st_d[wv][r] = ld4; st_slot[wv][r] = l_base + lane;
+            }
+            s_n = (unsigned int) __popcll(m); s_pos = 0; loading = false;
+        }
+        if (!loading && b_next < n_batches) {
+            l_base = b_next << 6;
+            const unsigned int sl = l_base + lane;
+            if (sl < n_slots) { lo4 = ANY ? pool.sh_o[sl] : pool.ray_o[sl]; ld4 = ANY ? pool.sh_d[sl] : pool.ray_d[sl]; }
+            else { lo4 = make_float4(0.f, 0.f, 0.f, 0.f); ld4 = make_float4(0.f, 0.f, 0.f, -1.f); }
+            loading = true; b_next += n_waves;
+        }
+        // ---- retire finished rays, hand out staged ones
         const unsigned long long fin = __ballot(tv.done());              // finished or never started
         if (PROF) { pf[0]++; pf[9] += 64 - __popcll(fin); }
         if (fin && (__popcll(fin) >= thr.z || fin == ~0ull)) {
             if (PROF) { pf[7]++; pf[8] += __popcll(__ballot(have && tv.done())); }
             if (have && tv.done()) {
-                // retire: hand the result to the pool
-                if (ANY) {
-                    float4 L = pool.li[slot];
-                    unsigned int flags = __float_as_uint(L.w);
-                    if (!tv.found) { float4 c = pool.sh_c[slot]; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
-                    if (flags & PF_ENDING) {
-                        float4 P = pool.pix[slot]; unsigned int pxy = __float_as_uint(P.z);
-                        if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), f3(L.x, L.y, L.z))) n_invalid++;
-                        L = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
-                    }
-                    pool.li[slot] = L;
-                } else {
-                    pool.hit[slot] = make_uint4(tv.hit.pos, __float_as_uint(tv.hit.t), __float_as_uint(tv.hit.u), __float_as_uint(tv.hit.v));
-                }
+                if (ANY) { if (!tv.found) reinterpret_cast<float *>(pool.sh_c + slot)[3] = 1.0f; }
+                else pool.hit[slot] = make_uint4(tv.hit.pos, __float_as_uint(tv.hit.t), __float_as_uint(tv.hit.u), __float_as_uint(tv.hit.v));
                 have = false;
             }
-            while (cursor >= end && !drained) {
-                const unsigned int s_lo = seg * seg_len, s_hi = (s_lo + seg_len < n) ? s_lo + seg_len : n;
-                unsigned int base = 0xffffffffu;
-                if (s_lo < n) { if (lane == 0) base = atomicAdd(&CN_HEAD(cnt, ANY, seg), ND_GRAB); base = __builtin_amdgcn_readfirstlane(base); }
-                if (s_lo < n && base < s_hi - s_lo) { cursor = s_lo + base; end = (cursor + ND_GRAB < s_hi) ? cursor + ND_GRAB : s_hi; seg_tried = 0; }
-                else { seg = (seg + 1) % ND_SEG; if (++seg_tried >= ND_SEG) drained = true; }
-            }
-            if (cursor < end) {
-                const unsigned int idx = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
-                if (tv.done() && idx < end) {
-                    slot = queue[idx];
-                    float4 ro = ANY ? pool.sh_o[slot] : pool.ray_o[slot], rd = ANY ? pool.sh_d[slot] : pool.ray_d[slot];
+            if (s_pos < s_n) {
+                const unsigned int idx = s_pos + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
+                if (tv.done() && idx < s_n) {
+                    const float4 ro = st_o[wv][idx], rd = st_d[wv][idx]; slot = st_slot[wv][idx];
                     Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
-                    if (!(r.maxt < r.mint)) n_rays++;
-                    have = true;
+                    n_rays++; have = true;
                     tv.begin(sc, r, n_boxes);
                 }
-                cursor += (unsigned int) __popcll(fin);
+                s_pos += (unsigned int) __popcll(fin);
             }
-            if (drained && cursor >= end && __ballot(have) == 0ull) break;   // queue consumed and nothing in flight
+            if (!loading && s_pos >= s_n && b_next >= n_batches && __ballot(have) == 0ull) break;   // nothing staged, loading or in flight
         }
+        // ---- traversal steps
         const unsigned long long m_in = __ballot(tv.at_inner());
         bool ran = false;
         if (m_in && (__popcll(m_in) >= thr.x || __ballot(tv.at_leaf()) == 0ull)) {
             if (PROF) { pf[1]++; pf[2] += __popcll(m_in); }
-            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(sc, stk, n_boxes); }
-            else if (tv.at_inner()) tv.box_step(sc, stk, n_boxes);
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, n_boxes); }
+            else if (tv.at_inner()) tv.box_step(nodes, stk, n_boxes);
             ran = true;
         }
         const unsigned long long m_lf = __ballot(tv.at_leaf());
@@ -464,31 +474,32 @@ __global__ __launch_bounds__(256) void k_trace_queue(DevScene sc, Pool pool, flo
         if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
         if (tv.at_pop()) tv.pop_step(stk);
     }
-    unsigned long long v[4] = {n_rays, n_boxes, n_prims, n_invalid};
-    for (int k = 0; k < 4; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
+    unsigned long long v[3] = {n_rays, n_boxes, n_prims};
+    for (int k = 0; k < 3; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
     if (lane == 0 && (v[0] | v[1])) {
         DevStats *st = my_stats(stats);
         atomicAdd(ANY ? &st->shadow : &st->closest, v[0]); atomicAdd(&st->nodes, v[1]); atomicAdd(&st->prims, v[2]);
-        if (v[3]) atomicAdd(&st->invalid, v[3]);
         if (PROF) for (int k = 0; k < 10; ++k) atomicAdd(&st->prof[ANY ? 1 : 0][k], (unsigned long long) pf[k]);
     }
 }
 
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
-// stage launch per bounce would be mostly launch latency.  Each lane takes one surviving slot (its closest hit is
-// already in the pool) and runs its path to the end.
-__global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *queue, WfCounters *cnt, int cur, DevStats *stats) {
-    const unsigned int n = CN_ACTIVE(cnt, cur);
-    ScratchStack stk; Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
+// stage launch per bounce would be mostly launch latency.  Each lane takes one surviving slot of the live list
+// (its closest hit and shadow result are already in the pool) and runs its path to the end.
+__global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
+    __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
+    const unsigned int n = CN_LIVE(cnt);
+    LdsStack stk; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + (threadIdx.x & 63u);
+    Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned int slot = queue[i];
+        const unsigned int slot = q_live[i];
         float4 L = pool.li[slot];
         unsigned int flags = __float_as_uint(L.w);
-        if (!(flags & PF_ACTIVE) || (flags & PF_ENDING)) continue;       // already splatted by the shadow stage
+        if (!(flags & PF_ACTIVE)) continue;
         uint4 h = pool.hit[slot];
         float4 P = pool.pix[slot];
-        PathState ps; ps.li = f3(L.x, L.y, L.z);
-        if (h.x != 0xffffffffu) {
+        PathState ps; ps.li = add_pending_nee(f3(L.x, L.y, L.z), flags, pool.sh_c[slot]);
+        if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
             float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; uint4 R = pool.rng[slot];
             ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
             ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
@@ -509,6 +520,7 @@ __global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *
         unsigned int pxy = __float_as_uint(P.z);
         if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
         pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+        pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f); pool.sh_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);
     }
     unsigned long long v[5] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
     for (int k = 0; k < 5; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
@@ -600,15 +612,17 @@ struct NoriHipContext {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     NoriHipStats stats;
     int n_cus = 256;
+    size_t lds_bytes = 65536;         // LDS a workgroup may use (sharedMemPerBlockOptin)
     // wavefront pipeline
     unsigned int pool_slots = 0; Pool pool; void *pool_mem = nullptr;
-    unsigned int *d_queue[2] = {nullptr, nullptr}, *d_qshadow = nullptr, *d_flags = nullptr; WfCounters *d_cnt = nullptr;
+    unsigned int *d_qlive = nullptr, *d_flags = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
-    bool lds_stack = true;            // traversal stack of the trace stages: LDS (+ scratch spill) or scratch only
     unsigned int finish_below = 32768;
     int shade_blocks_per_cu = 6;      // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 6;      // persistent trace waves: resident blocks per CU (LDS stack: 24.5 KB per block)
+    int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
+    int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 24, thr_prim = 16, thr_refill = 16;   // k_trace_queue step thresholds (lanes)
     void free_scene() {
@@ -635,6 +649,8 @@ int nori_hip_create(int device, NoriHipContext **out) {
     c->device = device;
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device));
     c->n_cus = prop.multiProcessorCount;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) c->lds_bytes = (size_t) v; }
+    if (const char *e = getenv("NORI_HIP_LDS")) { long v = atol(e); if (v >= 16384 && v <= 163840) c->lds_bytes = (size_t) v; }
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipMalloc((void **) &c->d_counter, sizeof(unsigned long long)));
@@ -642,10 +658,11 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipMemset(c->d_stats, 0, ND_STRIPES * sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) c->pipeline = (std::string(e) == "mega") ? 0 : 1;
-    if (const char *e = getenv("NORI_HIP_STACK")) c->lds_stack = std::string(e) != "scratch";
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->trace_blocks_per_cu = v; }
+    if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
+    if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
     if (const char *e = getenv("NORI_HIP_PROFILE")) c->profile = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
         int a, b, d; if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 1 && b >= 1 && d >= 1 && a <= 64 && b <= 64 && d <= 64) { c->thr_box = a; c->thr_prim = b; c->thr_refill = d; }
@@ -665,7 +682,7 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
     hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
-    hipFree(ctx->d_queue[0]); hipFree(ctx->d_queue[1]); hipFree(ctx->d_qshadow); hipFree(ctx->d_flags);
+    hipFree(ctx->d_qlive); hipFree(ctx->d_flags);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
@@ -710,7 +727,31 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->free_scene();
     int rc;
-    if ((rc = upload(ctx->d_nodes, d->nodes, d->n_nodes))) return rc;
+    // Renumber the inner nodes so that the top of the tree comes first, in breadth-first order: kernels keep a prefix
+    // of the node array in LDS and test `index < cached`.  Only the numbering changes; boxes, child order and the
+    // leaf records are the caller's.
+    uint32_t root = d->root, n_top = 0;
+    {
+        std::vector<NoriHipNode> nodes(d->nodes, d->nodes + d->n_nodes);
+        if (d->n_nodes > 0 && !(d->root & NORI_HIP_LEAF_BIT)) {
+            const uint32_t top_max = std::min<uint32_t>(d->n_nodes, 2560u);      // 160 KB of LDS / 64 B
+            std::vector<uint32_t> bfs; bfs.reserve(top_max); bfs.push_back(d->root);
+            std::vector<uint32_t> new_of(d->n_nodes, 0xffffffffu);
+            for (size_t k = 0; k < bfs.size() && bfs.size() < top_max; ++k) {
+                const NoriHipNode &nd_ = d->nodes[bfs[k]];
+                for (uint32_t ch : {nd_.left, nd_.right})
+                    if (ch != NORI_HIP_NO_CHILD && !(ch & NORI_HIP_LEAF_BIT) && bfs.size() < top_max) bfs.push_back(ch);
+            }
+            n_top = (uint32_t) bfs.size();
+            for (uint32_t k = 0; k < n_top; ++k) new_of[bfs[k]] = k;
+            uint32_t next = n_top;
+            for (uint32_t i = 0; i < d->n_nodes; ++i) if (new_of[i] == 0xffffffffu) new_of[i] = next++;
+            auto map_ref = [&](uint32_t r) { return (r == NORI_HIP_NO_CHILD || (r & NORI_HIP_LEAF_BIT)) ? r : new_of[r]; };
+            for (uint32_t i = 0; i < d->n_nodes; ++i) { NoriHipNode t = d->nodes[i]; t.left = map_ref(t.left); t.right = map_ref(t.right); nodes[new_of[i]] = t; }
+            root = new_of[d->root];
+        }
+        if ((rc = upload(ctx->d_nodes, nodes.data(), d->n_nodes))) return rc;
+    }
     if ((rc = upload(ctx->d_prims, d->prims, d->n_prims))) return rc;
     if ((rc = upload(ctx->d_shade, d->shade_prims, d->n_prims))) return rc;
     if ((rc = upload(ctx->d_light, d->light_prims, d->n_light_prims))) return rc;
@@ -720,7 +761,7 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     DevScene &sc = ctx->sc;
     sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
-    sc.root = d->root; sc.n_emitters = d->n_emitters;
+    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes;
     for (int i = 0; i < 3; ++i) { sc.root_min[i] = d->root_min[i]; sc.root_max[i] = d->root_max[i]; }
     sc.cam = d->camera;
     sc.inv_w = 1.0f / (float) d->camera.width; sc.inv_h = 1.0f / (float) d->camera.height;
@@ -812,12 +853,20 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (ctx->pipeline == 0) {
         // single persistent kernel with per-lane path regeneration
-        unsigned long long chunks = (job.total + 255) / 256;
-        unsigned blocks = (unsigned) ctx->n_cus * 8u;
+        unsigned long long chunks = (job.total + MEGA_THREADS - 1) / MEGA_THREADS;
+        const int W = ctx->mega_waves;
+        unsigned blocks = (unsigned) ctx->n_cus * (unsigned) W;                    // W waves per SIMD = W workgroups of 4 waves per CU
         if ((unsigned long long) blocks > chunks) blocks = (unsigned) chunks;
         if (blocks == 0) blocks = 1;
+        const size_t stack_bytes = (size_t) (MEGA_THREADS / 64) * MEGA_DEPTH * 64 * 8;
+        const size_t share = std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) W) & ~(size_t) 1023;
+        const unsigned int n_cached = share > stack_bytes ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((share - stack_bytes) / 64)) : 0u;
+        const size_t lds = stack_bytes + (size_t) n_cached * 64;
+        void (*kern)(DevScene, RenderJob, float4 *, unsigned long long *, DevStats *, unsigned int) =
+            W == 3 ? k_render_w3 : W == 4 ? k_render_w4 : W == 5 ? k_render_w5 : W == 6 ? k_render_w6 : k_render_w8;
+        HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(MEGA_THREADS), lds, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats, n_cached);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         ctx->stats.iterations = 1;
@@ -831,40 +880,34 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         Pool &pl = ctx->pool;
         pl.ray_o = base; pl.ray_d = base + P; pl.hit = (uint4 *) (base + 2 * P); pl.thr = base + 3 * P; pl.li = base + 4 * P;
         pl.rng = (uint4 *) (base + 5 * P); pl.pix = base + 6 * P; pl.sh_o = base + 7 * P; pl.sh_d = base + 8 * P; pl.sh_c = base + 9 * P;
-        HIPCHK(hipMalloc((void **) &ctx->d_queue[0], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_queue[1], P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_qshadow, P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_flags, P * 4));
+        HIPCHK(hipMalloc((void **) &ctx->d_qlive, P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_flags, P * 4));
     }
     unsigned int P = ctx->pool_slots;
     if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, ctx->d_queue[0], P, ctx->d_cnt);
-    const bool lds = ctx->lds_stack;
+    WfCounters *c = ctx->d_cnt;
+    hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
     const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
     const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below, P);
+    const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->trace_blocks_per_cu));
+    const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
-    int cur = 0; uint64_t it = 0;
+    uint64_t it = 0;
     for (;; ++it) {
-        WfCounters *c = ctx->d_cnt;
-        // grids sized by the (stale, hence conservative) live count: up to two rounds of resident waves
-        const unsigned trace_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->trace_blocks_per_cu));
-        const unsigned shade_blocks = std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
-        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, ctx->stream, c, cur);
-        hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, job, ctx->d_film, (const unsigned int *) ctx->d_queue[cur],
-                           ctx->d_queue[1 - cur], ctx->d_qshadow, ctx->d_flags, c, cur, ctx->d_counter, ctx->d_stats);
-        {
-            const unsigned int *qs = ctx->d_qshadow, *qe = ctx->d_queue[1 - cur];
-#define ND_LAUNCH_TRACE(L, PR) \
-            hipLaunchKernelGGL((k_trace_queue<true, L, PR>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, qs, c, 1 - cur, ctx->d_stats, thr); \
-            hipLaunchKernelGGL((k_trace_queue<false, L, PR>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, qe, c, 1 - cur, ctx->d_stats, thr);
-            if (ctx->profile) { if (lds) { ND_LAUNCH_TRACE(true, true) } else { ND_LAUNCH_TRACE(false, true) } }
-            else { if (lds) { ND_LAUNCH_TRACE(true, false) } else { ND_LAUNCH_TRACE(false, false) } }
-#undef ND_LAUNCH_TRACE
+        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
+        hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, job, ctx->d_film, ctx->d_qlive, ctx->d_flags, c, ctx->d_counter, ctx->d_stats);
+        if (ctx->profile) {
+            hipLaunchKernelGGL((k_trace_pool<true, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
+            hipLaunchKernelGGL((k_trace_pool<false, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
+        } else {
+            hipLaunchKernelGGL((k_trace_pool<true, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
+            hipLaunchKernelGGL((k_trace_pool<false, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
         }
         HIPCHK(hipGetLastError());
         // the live count comes back through a 4-deep ring of pinned words, so the host runs at most three iterations
         // ahead of the device and never waits on the iteration it has just queued
-        HIPCHK(hipMemcpyAsync(&ctx->h_ring[it & 3], &CN_ACTIVE(c, 1 - cur), sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(&ctx->h_ring[it & 3], &CN_LIVE(c), sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipEventRecord(ctx->ring_ev[it & 3], ctx->stream));
-        cur = 1 - cur;
         if (it >= 3) {
             HIPCHK(hipEventSynchronize(ctx->ring_ev[(it - 3) & 3]));
             n_upper = ctx->h_ring[(it - 3) & 3];
@@ -872,7 +915,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
                 hipLaunchKernelGGL(k_finish, dim3(std::max(1u, (n_upper + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film,
-                                   (const unsigned int *) ctx->d_queue[cur], c, cur, ctx->d_stats);
+                                   (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
                 ++it;
                 break;
