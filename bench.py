@@ -167,7 +167,16 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     st = ctx.stats()
-    kernel_ms = st["render_ms"]                           # HIP events around the last k_render launch, on its stream
+    # dominant kernel: the extend stage (k_trace_pool<closest>) of the wavefront pipeline, timed by the library with
+    # HIP events around every one of its launches on the context's stream; with NORI_HIP_PIPELINE=mega the single
+    # persistent kernel (k_render_w4), timed the same way around its last launch
+    wavefront = st["extend_launches"] > 0
+    if wavefront:
+        launches = st["extend_launches"]
+        kernel_ms = st["extend_ms"] / launches
+        k_rays, k_boxes, k_prims = st["extend_rays"] / launches, st["extend_boxes"] / launches, st["extend_prims"] / launches
+    else:
+        kernel_ms = st["render_ms"]
     if dist is not None:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -181,8 +190,21 @@ def main():
     rays = (st["closest_rays"] + st["shadow_rays"]) / args.steps            # this rank, per step
     # algorithmic bytes per step: 32 B per node box tested + 40 B per primitive tested
     # + 44 B ray in + 16 B hit out per ray + 2 x 16 B film read-modify-write per camera sample
-    alg_bytes = (32.0 * st["boxes_tested"] + 40.0 * st["prims_tested"]) / args.steps + 60.0 * rays + 32.0 * samples_per_step
+    if wavefront:
+        alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays              # per extend launch
+        kname = "k_trace_pool<false,false>"
+    else:
+        alg_bytes = (32.0 * st["boxes_tested"] + 40.0 * st["prims_tested"]) / args.steps + 60.0 * rays + 32.0 * samples_per_step
+        kname = "k_render_w4"
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, scratch/pmc.sh), which
+    # cannot run inside this process: the committed measurement of this workload and pipeline, if there is one
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.workload)
+    if os.path.exists(tpath) and not args.spp:
+        tj = json.load(open(tpath))
+        if tj.get("kernel") == kname:
+            traffic = int(tj["traffic_bytes_per_launch"])
     out = {
         "metric": "Msamples/s (path_mis, whole node)", "value": round(total_samples / dt / 1e6, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -192,9 +214,9 @@ def main():
                    "scene_load_s": round(load_s, 2), "bvh_build_s": round(hs.bvh_build_seconds(), 3)},
         "mrays_per_s": round(rays * world * args.steps / dt / 1e6, 2),
         "rays_per_sample": round(rays / samples_per_step, 3),
-        "roofline": {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel_ms": round(kernel_ms, 4), "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
                      "boxes_tested_per_ray": round(st["boxes_tested"] / args.steps / rays, 2), "prims_tested_per_ray": round(st["prims_tested"] / args.steps / rays, 2)},
     }
     if not args.no_cpu and world == 1:

@@ -36,7 +36,7 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
 // Every counter the kernels bump therefore sits on a line of its own, and the hot ones are striped over ND_STRIPES
 // lines that the reader sums.
 #define ND_STRIPES 32
-struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims; unsigned long long prof[2][10]; };
+struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims, ext_rays, ext_nodes, ext_prims; unsigned long long prof[2][10]; };
 __device__ __forceinline__ DevStats *my_stats(DevStats *stats) { return stats + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ND_STRIPES - 1)); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -264,7 +264,7 @@ __device__ __forceinline__ F3 add_pending_nee(F3 li, unsigned int flags, float4 
 //   pass B  starts new paths in the freed slots from the reserved work items (src/render.cpp:83-98) and writes the
 //           live list (used by the host for termination and by k_finish)
 enum { SF_REGEN = 1u, SF_KEEP = 2u, SF_IDLE = 4u };
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
                                                unsigned int *flag_buf, WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
     __shared__ unsigned int w_tot[4][2];
     __shared__ unsigned long long b_work; __shared__ unsigned int b_live;
@@ -400,9 +400,10 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, Pool pool, unsigned 
 // The steps are straight-line code.  At least one step runs per trip, so the loop always makes progress; it ends
 // when the wave's batches are used up and every lane has retired its ray.  Results leave through plain stores:
 // the hit record (extend) or the visibility word sh_c.w (shadow).
+#define TRACE_DEPTH 6
 template <bool ANY, bool PROF>
 __global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr) {
-    __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
+    __shared__ uint2 lds_stack[4 * TRACE_DEPTH * 64];
     __shared__ float4 st_o[4][64], st_d[4][64];
     __shared__ unsigned int st_slot[4][64];
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsi
     bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
-    LdsStack stk; stk.base = (lds_u64 *) lds_stack + wv * (LDS_DEPTH * 64) + lane;
+    LdsStackT<TRACE_DEPTH> stk; stk.base = (lds_u64 *) lds_stack + wv * (TRACE_DEPTH * 64) + lane;
     GlobalNodes nodes; nodes.nodes = sc.nodes;
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
     bool have = false; unsigned int slot = 0;
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsi
     if (lane == 0 && (v[0] | v[1])) {
         DevStats *st = my_stats(stats);
         atomicAdd(ANY ? &st->shadow : &st->closest, v[0]); atomicAdd(&st->nodes, v[1]); atomicAdd(&st->prims, v[2]);
+        if (!ANY) { atomicAdd(&st->ext_rays, v[0]); atomicAdd(&st->ext_nodes, v[1]); atomicAdd(&st->ext_prims, v[2]); }
         if (PROF) for (int k = 0; k < 10; ++k) atomicAdd(&st->prof[ANY ? 1 : 0][k], (unsigned long long) pf[k]);
     }
 }
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsi
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
 // stage launch per bounce would be mostly launch latency.  Each lane takes one surviving slot of the live list
 // (its closest hit and shadow result are already in the pool) and runs its path to the end.
-__global__ __launch_bounds__(256) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
     __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
     const unsigned int n = CN_LIVE(cnt);
     LdsStack stk; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + (threadIdx.x & 63u);
@@ -617,14 +619,26 @@ struct NoriHipContext {
     unsigned int pool_slots = 0; Pool pool; void *pool_mem = nullptr;
     unsigned int *d_qlive = nullptr, *d_flags = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ext_ev;   // pairs of events around the extend launches since the last reset_stats
+    size_t ext_used = 0; double ext_ms_acc = 0.0; uint64_t ext_launches = 0;
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
-    unsigned int finish_below = 32768;
+    unsigned int finish_below = 0;    // live paths below which k_finish takes over; 0 = a quarter of the pool (NORI_HIP_FINISH)
     int shade_blocks_per_cu = 6;      // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 6;      // persistent trace waves: resident blocks per CU (LDS stack: 24.5 KB per block)
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
-    int thr_box = 24, thr_prim = 16, thr_refill = 16;   // k_trace_queue step thresholds (lanes)
+    int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_queue step thresholds (lanes)
+    // adds the elapsed time of the recorded extend launches to ext_ms_acc (waits for them)
+    int fold_ext_events() {
+        for (size_t k = 0; k + 1 < ext_used; k += 2) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ext_ev[k + 1]) != hipSuccess || hipEventElapsedTime(&ms, ext_ev[k], ext_ev[k + 1]) != hipSuccess) { (void) hipGetLastError(); continue; }
+            ext_ms_acc += ms; ext_launches++;
+        }
+        ext_used = 0;
+        return NORI_HIP_OK;
+    }
     void free_scene() {
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
@@ -667,7 +681,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
         int a, b, d; if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 1 && b >= 1 && d >= 1 && a <= 64 && b <= 64 && d <= 64) { c->thr_box = a; c->thr_prim = b; c->thr_refill = d; }
     }
-    c->pool_slots = 1u << 20;
+    c->pool_slots = 1u << 22;
     if (const char *e = getenv("NORI_HIP_POOL")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) c->pool_slots = (unsigned int) v; }
     HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
     HIPCHK(hipHostMalloc((void **) &c->h_ring, 4 * sizeof(unsigned int), hipHostMallocDefault));
@@ -685,6 +699,7 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     hipFree(ctx->d_qlive); hipFree(ctx->d_flags);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
+    for (hipEvent_t e : ctx->ext_ev) hipEventDestroy(e);
     hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -888,7 +903,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     WfCounters *c = ctx->d_cnt;
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
     const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
-    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below, P);
+    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : ctx->pool_slots / 4, P);
     const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->trace_blocks_per_cu));
     const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
@@ -901,7 +916,14 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
             hipLaunchKernelGGL((k_trace_pool<false, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
         } else {
             hipLaunchKernelGGL((k_trace_pool<true, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
+            if (ctx->ext_used + 2 > ctx->ext_ev.size()) {
+                if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
+                else { hipEvent_t a_, b_; HIPCHK(hipEventCreate(&a_)); HIPCHK(hipEventCreate(&b_)); ctx->ext_ev.push_back(a_); ctx->ext_ev.push_back(b_); }
+            }
+            HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
             hipLaunchKernelGGL((k_trace_pool<false, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
+            HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used + 1], ctx->stream));
+            ctx->ext_used += 2;
         }
         HIPCHK(hipGetLastError());
         // the live count comes back through a 4-deep ring of pinned words, so the host runs at most three iterations
@@ -1003,6 +1025,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     HIPCHK(hipMemcpy(stripes.data(), ctx->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
     DevStats ds; std::memset(&ds, 0, sizeof(ds));
     for (const DevStats &t : stripes) {
+        ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims;
         ds.samples += t.samples; ds.closest += t.closest; ds.shadow += t.shadow; ds.invalid += t.invalid; ds.nodes += t.nodes; ds.prims += t.prims;
         for (int k = 0; k < 2; ++k) for (int j = 0; j < 10; ++j) ds.prof[k][j] += t.prof[k][j];
     }
@@ -1010,6 +1033,9 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->stats.render_ms = ms; else (void) hipGetLastError();
     ctx->stats.boxes_tested = ds.nodes; ctx->stats.prims_tested = ds.prims;
+    ctx->fold_ext_events();
+    ctx->stats.extend_ms = ctx->ext_ms_acc; ctx->stats.extend_launches = ctx->ext_launches;
+    ctx->stats.extend_rays = ds.ext_rays; ctx->stats.extend_boxes = ds.ext_nodes; ctx->stats.extend_prims = ds.ext_prims;
     if (ctx->profile) {
         static const char *names[10] = {"trips", "box_runs", "box_lanes", "prim_runs", "prim_lanes", "pop_runs", "pop_lanes", "refill_runs", "retired", "busy_lanes"};
         for (int k = 0; k < 2; ++k) {
@@ -1024,6 +1050,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
 int nori_hip_reset_stats(NoriHipContext *ctx) {
     CTXCHK(ctx);
     HIPCHK(hipMemsetAsync(ctx->d_stats, 0, ND_STRIPES * sizeof(DevStats), ctx->stream));
+    ctx->fold_ext_events(); ctx->ext_ms_acc = 0.0; ctx->ext_launches = 0;
     return NORI_HIP_OK;
 }
 int nori_hip_stream(NoriHipContext *ctx, void **stream) { CTXCHK(ctx); if (stream) *stream = ctx->stream; return NORI_HIP_OK; }

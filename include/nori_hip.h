@@ -127,7 +127,9 @@ typedef struct NoriHipStats {
     uint64_t prims_tested;         /* ray/primitive tests performed */
     uint64_t iterations;           /* wavefront iterations of the last render call */
     double   render_ms;            /* device time of the last render call (HIP events on the context stream) */
-    double   extend_ms, shade_ms, shadow_ms;   /* per-stage device time of the last render call (0 if not collected) */
+    double   extend_ms;            /* device time of the extend-stage launches (k_trace_pool<closest>) since the last reset_stats, HIP events */
+    uint64_t extend_launches;      /* how many launches extend_ms covers (0: the single-kernel pipeline ran) */
+    uint64_t extend_rays, extend_boxes, extend_prims;   /* work of those launches */
 } NoriHipStats;
 
 typedef struct NoriHipContext NoriHipContext;
