@@ -7,8 +7,8 @@ renders its own spp slice of the same image (weak scaling: per-GPU work is fixed
 over ranks with one RCCL all-reduce per step, inside the timed region.
 
 Workloads (BASELINE.json configs):
-  cbox   scenes/cbox/cbox_path_mis.xml at 512x512, 64 spp      (config 1 / the metric's "cbox")
-  table  scenes/table/table_path_mis_microfacet.xml 800x600, 256 spp   (config 2)
+  table  scenes/table/table_path_mis_microfacet.xml 800x600, 256 spp   (configs[1]: the single-GPU configuration; default)
+  cbox   scenes/cbox/cbox_path_mis.xml at 512x512, 64 spp      (configs[0], the reference's CPU-runnable case)
   c4     synthetic ~10M-triangle height field under area lights, 1024x1024, 16 spp (config 4)
 """
 import argparse
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cbox", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="table", choices=list(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--cpu-spp", type=int, default=192)
     ap.add_argument("--no-cpu", action="store_true")
@@ -118,6 +118,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     import torch
     import nori_hip as NH
+    from nori_hip.partition import spp_slice, allreduce_film
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -142,10 +143,10 @@ def main():
 
     def step(k):
         ctx.clear_film()
-        ctx.render(rank * spp, (rank + 1) * spp)          # this rank's spp slice
+        ctx.render(*spp_slice(rank, world, spp))          # this rank's spp slice
         if film is not None:
             ctx.synchronize()                             # film complete before the collective reads it
-            dist.all_reduce(film)
+            allreduce_film(film, dist)
 
     def sync():
         ctx.synchronize()

@@ -681,8 +681,8 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
         int a, b, d; if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 1 && b >= 1 && d >= 1 && a <= 64 && b <= 64 && d <= 64) { c->thr_box = a; c->thr_prim = b; c->thr_refill = d; }
     }
-    c->pool_slots = 1u << 22;
-    if (const char *e = getenv("NORI_HIP_POOL")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) c->pool_slots = (unsigned int) v; }
+    c->pool_slots = 0;                 // 0: sized per render call (a quarter of the call's paths, between 1M and 8M slots)
+    if (const char *e = getenv("NORI_HIP_POOL")) { long v = atol(e); if (v >= 64 && v <= (1l << 26)) c->pool_slots = (unsigned int) v; }
     HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
     HIPCHK(hipHostMalloc((void **) &c->h_ring, 4 * sizeof(unsigned int), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
@@ -888,8 +888,9 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         return NORI_HIP_OK;
     }
     // ---- wavefront stages over a pool of path slots
+    const unsigned int pool_cap = ctx->pool_slots ? ctx->pool_slots : (1u << 23);
     if (!ctx->pool_mem) {
-        const size_t P = ctx->pool_slots;
+        const size_t P = pool_cap;
         HIPCHK(hipMalloc(&ctx->pool_mem, P * 10 * sizeof(float4)));
         float4 *base = (float4 *) ctx->pool_mem;
         Pool &pl = ctx->pool;
@@ -897,13 +898,14 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         pl.rng = (uint4 *) (base + 5 * P); pl.pix = base + 6 * P; pl.sh_o = base + 7 * P; pl.sh_d = base + 8 * P; pl.sh_c = base + 9 * P;
         HIPCHK(hipMalloc((void **) &ctx->d_qlive, P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_flags, P * 4));
     }
-    unsigned int P = ctx->pool_slots;
+    unsigned int P = pool_cap;
+    if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, (job.total / 4 + 65535) & ~65535ull));
     if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     WfCounters *c = ctx->d_cnt;
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
     const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
-    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : ctx->pool_slots / 4, P);
+    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : P / 4, P);
     const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->trace_blocks_per_cu));
     const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)

@@ -4,7 +4,7 @@ tag=$1; shift
 for e in "$@"; do export "$e"; done
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/kt_$tag
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/kt_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/kt_$tag.log 2>&1 || { tail -5 $GRAFT_REPO_ROOT/gpurun_out/kt_$tag.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/kt_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/kt_$tag.log 2>&1 || { tail -5 $GRAFT_REPO_ROOT/gpurun_out/kt_$tag.log; exit 1; }
 cd $GRAFT_REPO_ROOT
 grep ms_per_step gpurun_out/kt_$tag.log | cut -c1-200
 python3 - $tag <<'PY'

@@ -139,9 +139,11 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
     W, H, spp = 80, 56, 6
     films, stats = [], []
     configs = [dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="4096"),
-               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="4096", NORI_HIP_STACK="scratch", NORI_HIP_FINISH="0"),
-               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="1048576"),
-               dict(NORI_HIP_PIPELINE="mega")]
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="4096", NORI_HIP_FINISH="1", NORI_HIP_THR="24,16,16"),   # stages to the last path
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="1000", NORI_HIP_FINISH="900"),       # ragged pool, early hand-over
+               dict(NORI_HIP_PIPELINE="wavefront"),
+               dict(NORI_HIP_PIPELINE="mega"),
+               dict(NORI_HIP_PIPELINE="mega", NORI_HIP_MEGA_WAVES="6", NORI_HIP_LDS="20480")]
     for env in configs:
         os.environ.update(env)
         try:
