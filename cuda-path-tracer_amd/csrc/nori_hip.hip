@@ -4,10 +4,12 @@
 //   k_trace        one ray per lane, closest- or any-hit (BVH::rayIntersect, src/bvh.cpp:404-463)
 //   k_camera_rays  PerspectiveCamera::sampleRay (src/perspective.cpp:90-111)
 //   k_li_samples   one camera sample per lane, seeded per sample (parity entry)
-//   k_render       persistent lanes with per-lane path regeneration: every lane runs one bounce of
-//                  PathMisIntegrator::Li per loop trip (extend -> shade -> shadow), and a lane whose path ended
-//                  splats it to the film and draws the next camera sample from a global counter, so waves stay
-//                  full until the work runs out (src/render.cpp:72-101 + src/pathMisIntegrator.cpp:18-168)
+//   k_shade, k_trace_pool<any|closest>, k_finish
+//                  the default render pipeline: PathMisIntegrator::Li (src/pathMisIntegrator.cpp:18-168) and the
+//                  render loop (src/render.cpp:72-101) as stages over a pool of path slots (see "Wavefront pipeline")
+//   k_render_wN    NORI_HIP_PIPELINE=mega: persistent lanes with per-lane path regeneration; every lane runs one
+//                  bounce per loop trip (extend -> shade -> shadow), a lane whose path ended splats it to the film
+//                  and takes the next camera sample; N = waves per SIMD the variant is built for
 //   k_bitmap       ImageBlock::toBitmap (src/block.cpp:76-82)
 //   k_srgb, k_nlmeans   the filter pass of the CUDA fork (cuda/filter.cc.cu:33-110)
 #include <hip/hip_runtime.h>
