@@ -626,7 +626,7 @@ struct NoriHipContext {
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
     unsigned int finish_below = 0;    // live paths below which k_finish takes over; 0 = a quarter of the pool (NORI_HIP_FINISH)
     int shade_blocks_per_cu = 6;      // k_shade: blocks per CU (each block owns one contiguous run of the queue)
-    int trace_blocks_per_cu = 6;      // persistent trace waves: resident blocks per CU (LDS stack: 24.5 KB per block)
+    int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
@@ -676,7 +676,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_PIPELINE")) c->pipeline = (std::string(e) == "mega") ? 0 : 1;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
-    if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->trace_blocks_per_cu = v; }
+    if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
     if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
     if (const char *e = getenv("NORI_HIP_PROFILE")) c->profile = atoi(e) != 0;
@@ -908,7 +908,16 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
     const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
     const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : P / 4, P);
-    const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->trace_blocks_per_cu));
+    // the trace stages give every wave a static share of the pool, so all their workgroups must be resident at once
+    int trace_bpc = ctx->trace_blocks_per_cu;
+    if (trace_bpc == 0) {
+        int occ_e = 0, occ_s = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, (const void *) k_trace_pool<false, false>, 256, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, (const void *) k_trace_pool<true, false>, 256, 0));
+        trace_bpc = std::max(1, std::min(occ_e, occ_s));
+        if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage occupancy: %d / %d workgroups per CU\n", occ_e, occ_s);
+    }
+    const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
     const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     uint64_t it = 0;
