@@ -192,3 +192,89 @@ def test_error_behaviour(loaded):
     with pytest.raises(NH.NoriHipError, match="child reference out of range"):
         c2.upload(C.pointer(d))
     c2.close()
+
+
+def _degenerate_rays(n, seed, lo, hi):
+    """rays that take the general box-test path (a zero, negative-zero or denormal direction component), rays that
+    start exactly on box planes, empty and unbounded intervals, and the adaptive-epsilon case mint == 1e-4"""
+    rng = np.random.default_rng(seed)
+    o = (lo + rng.random((n, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    kind = rng.integers(0, 8, n)
+    for i in range(n):
+        k = kind[i]
+        if k == 0:                                  # axis-aligned: two zero components
+            a = rng.integers(0, 3); s = d[i, a]; d[i] = 0; d[i, a] = 1.0 if s >= 0 else -1.0
+        elif k == 1:                                # one zero component
+            d[i, rng.integers(0, 3)] = 0.0
+        elif k == 2:                                # negative zero
+            d[i, rng.integers(0, 3)] = -0.0
+        elif k == 3:                                # denormal component
+            d[i, rng.integers(0, 3)] = np.float32(1e-40) * (1 if rng.random() < 0.5 else -1)
+        elif k == 4:                                # origin on a scene-box plane, axis-aligned direction along another axis
+            a = rng.integers(0, 3); o[i, a] = lo[a] if rng.random() < 0.5 else hi[a]
+            b = (a + 1) % 3; d[i] = 0; d[i, b] = 1.0
+        elif k == 5:                                # origin snapped to a coarse grid (hits vertices/edges of the walls more often)
+            o[i] = np.round(o[i] * 4) / 4
+    nrm = np.linalg.norm(d, axis=1, keepdims=True); nrm[nrm == 0] = 1
+    d = (d / nrm).astype(np.float32)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = o; rays[:, 4:7] = d
+    rays[:, 3] = np.where(rng.random(n) < 0.3, np.float32(1e-4), np.float32(1e-3))
+    rays[:, 7] = np.inf
+    m = rng.random(n)
+    rays[m < 0.1, 7] = 0.5                          # short interval
+    rays[m < 0.03, 7] = -1.0                        # empty interval
+    return rays
+
+
+@pytest.mark.parametrize("name", ["cbox", "table"])
+def test_degenerate_rays_bit_exact_against_oracle(name, loaded):
+    hs, ctx = loaded(name, 64, 48)
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML[name]), 64, 48, 1)
+    P = hs.tables()["prims"]                                                  # scene bounds from the flattened records
+    tri = (P["shape_flags"] & 0x40000000) == 0
+    lo = P["a"][tri].min(0) - 0.05; hi = P["a"][tri].max(0) + 0.05
+    rays = _degenerate_rays(60000, 11, lo.astype(np.float32), hi.astype(np.float32))
+    got = ctx.trace(rays)
+    want = o.trace(rays)
+    assert np.array_equal(hits_as_u32(got), want)
+    got_any = ctx.trace(rays, any_hit=True)
+    want_any = o.trace(rays, any_hit=True)
+    assert np.array_equal(got_any["prim"] != 0xffffffff, want_any[:, 0] != 0xffffffff)
+    assert (want[:, 0] != 0xffffffff).mean() > 0.15                           # the set does hit geometry
+
+
+def test_empty_and_tiny_inputs(loaded):
+    hs, ctx = loaded("cbox", 64, 48)
+    assert len(ctx.trace(np.zeros((0, 8), np.float32))) == 0
+    assert ctx.camera_rays(np.zeros((0, 2), np.float32)).shape[0] == 0
+    # one pixel, one sample, through both pipelines' smallest launches
+    ctx.clear_film(); ctx.reset_stats()
+    ctx.render(0, 1, tile=(5, 7, 6, 8))
+    f = ctx.read_film()
+    assert f[:, :, 3].sum() == 1.0 and ctx.stats()["camera_samples"] == 1
+    # a ragged tile (not a multiple of the 8x8 work patches) over several calls equals one call
+    ctx.clear_film(); ctx.render(0, 3, tile=(3, 5, 30, 22)); a = ctx.read_film()
+    ctx.clear_film(); ctx.render(0, 1, tile=(3, 5, 30, 22)); ctx.render(1, 3, tile=(3, 5, 30, 22)); b = ctx.read_film()
+    assert np.array_equal(a[:, :, 3], b[:, :, 3]) and a[:, :, 3].sum() == 27 * 17 * 3
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_single_triangle_scene_has_a_dummy_root(loaded):
+    """one emissive triangle: the tree is a single leaf under a root with an absent right child (NORI_HIP_NO_CHILD)"""
+    sb = NH.SceneBuilder()
+    V = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    sb.add_mesh("tri", V, np.array([[0, 1, 2]], np.uint32), radiance=(2, 2, 2))
+    sb.set_camera((0, 0, 3), (0, 0, 0), (0, 1, 0), 40.0, 32, 32)
+    hs = sb.finish(spp=1)
+    ctx = hs.preprocess()
+    rays = np.zeros((3, 8), np.float32)
+    rays[:, 0:3] = [[0, 0, 3], [0.9, 0.9, 3], [0, 0, 3]]; rays[:, 4:7] = [[0, 0, -1], [0, 0, -1], [0, 0, 1]]
+    rays[:, 3] = 1e-3; rays[:, 7] = np.inf
+    h = ctx.trace(rays)
+    assert h["prim"][0] == 0 and h["t"][0] == 3.0 and h["prim"][1] == 0xffffffff and h["prim"][2] == 0xffffffff
+    ctx.render(0, 4)
+    img = ctx.read_bitmap()
+    assert img.max() == 2.0 and img.min() == 0.0                              # emitter seen directly, background black
+    hs.close()
