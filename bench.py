@@ -193,7 +193,7 @@ def main():
     # + 44 B ray in + 16 B hit out per ray + 2 x 16 B film read-modify-write per camera sample
     if wavefront:
         alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays              # per extend launch
-        kname = "k_trace_pool<false,false>"
+        kname = "k_trace_pool<TK_BOTH>" if os.environ.get("NORI_HIP_MERGE", "1") != "0" else "k_trace_pool<TK_EXTEND>"
     else:
         alg_bytes = (32.0 * st["boxes_tested"] + 40.0 * st["prims_tested"]) / args.steps + 60.0 * rays + 32.0 * samples_per_step
         kname = "k_render_w4"

@@ -237,7 +237,9 @@ template <bool ANY> struct Trav {
         cur = hl ? left : (hr ? right : ND_POP);
     }
     // one record of the current leaf; afterwards the lane is at the next record, in ND_POP (leaf finished) or done
-    __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) {
+    __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) { prim_step(sc, n_prims, ANY); }
+    // `any`: stop at the first hit (a per-lane flag where one kernel traces shadow and extend rays together)
+    __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims, const bool any) {
         const uint32_t pos = cur & 0x7fffffffu;
         const float4 *r = sc.prims + 3 * (size_t) pos;
         float4 A = r[0], B = r[1], C = r[2];
@@ -280,7 +282,7 @@ template <bool ANY> struct Trav {
         cur = (flags & 0x80000000u) ? ND_POP : (NORI_HIP_LEAF_BIT | (pos + 1u));
         if (h) {
             found = true;
-            if (ANY) { cur = ND_DONE; return; }
+            if (any) { cur = ND_DONE; return; }
             maxt = t; hit.pos = pos; hit.t = t; hit.u = u; hit.v = v;
         }
     }

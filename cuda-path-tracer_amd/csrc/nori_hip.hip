@@ -403,22 +403,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // when the wave's batches are used up and every lane has retired its ray.  Results leave through plain stores:
 // the hit record (extend) or the visibility word sh_c.w (shadow).
 #define TRACE_DEPTH 6
-template <bool ANY, bool PROF>
-__global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr) {
+// KIND: TK_EXTEND / TK_SHADOW trace one kind of ray; TK_BOTH traces the shadow rays and then the extend rays of
+// the pool in one launch (batches [0, NB) are shadow batches, [NB, 2 NB) extend batches; a lane carries the kind of
+// its ray), so an iteration has one kernel tail instead of two.
+enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
+template <int KIND, bool PROF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr) {
     __shared__ uint2 lds_stack[4 * TRACE_DEPTH * 64];
     __shared__ float4 st_o[4][64], st_d[4][64];
     __shared__ unsigned int st_slot[4][64];
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, n_batches = (n_slots + 63u) >> 6;
+    constexpr bool ANY = (KIND == TK_SHADOW);
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, nb_pool = (n_slots + 63u) >> 6, n_batches = (KIND == TK_BOTH) ? 2u * nb_pool : nb_pool;
     unsigned int b_next = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform: next batch to load
     bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
     LdsStackT<TRACE_DEPTH> stk; stk.base = (lds_u64 *) lds_stack + wv * (TRACE_DEPTH * 64) + lane;
     GlobalNodes nodes; nodes.nodes = sc.nodes;
+    bool any = ANY;                                                      // this lane's ray is a shadow ray
+    bool l_any = ANY;                                                    // wave-uniform: kind of the batch in flight
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
     bool have = false; unsigned int slot = 0;
-    uint32_t n_boxes = 0, n_prims = 0, n_rays = 0;
+    // statistics are wave-uniform sums of ballots (scalar registers): records and boxes tested, rays by kind
+    unsigned int n_boxes = 0, n_prims = 0, n_rays = 0, n_rays_any = 0;
+    uint32_t dummy = 0;
     unsigned int pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // PROF only: wave-uniform step statistics
     for (;;) {
         // ---- feed the staging pipeline
@@ -427,14 +436,15 @@ __global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsi
             const unsigned long long m = __ballot(valid);
             if (valid) {
                 const unsigned int r = __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
-                st_o[wv][r] = lo4; st_d[wv][r] = ld4; st_slot[wv][r] = l_base + lane;
+                st_o[wv][r] = lo4; st_d[wv][r] = ld4; st_slot[wv][r] = (l_base + lane) | ((KIND == TK_BOTH && l_any) ? 0x80000000u : 0u);
             }
             s_n = (unsigned int) __popcll(m); s_pos = 0; loading = false;
         }
         if (!loading && b_next < n_batches) {
-            l_base = b_next << 6;
+            l_any = (KIND == TK_BOTH) ? (b_next < nb_pool) : ANY;
+            l_base = ((KIND == TK_BOTH && !l_any) ? b_next - nb_pool : b_next) << 6;
             const unsigned int sl = l_base + lane;
-            if (sl < n_slots) { lo4 = ANY ? pool.sh_o[sl] : pool.ray_o[sl]; ld4 = ANY ? pool.sh_d[sl] : pool.ray_d[sl]; }
+            if (sl < n_slots) { lo4 = l_any ? pool.sh_o[sl] : pool.ray_o[sl]; ld4 = l_any ? pool.sh_d[sl] : pool.ray_d[sl]; }
             else { lo4 = make_float4(0.f, 0.f, 0.f, 0.f); ld4 = make_float4(0.f, 0.f, 0.f, -1.f); }
             loading = true; b_next += n_waves;
         }
@@ -444,18 +454,23 @@ __global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsi
         if (fin && (__popcll(fin) >= thr.z || fin == ~0ull)) {
             if (PROF) { pf[7]++; pf[8] += __popcll(__ballot(have && tv.done())); }
             if (have && tv.done()) {
-                if (ANY) { if (!tv.found) reinterpret_cast<float *>(pool.sh_c + slot)[3] = 1.0f; }
+                if ((KIND == TK_BOTH) ? any : ANY) { if (!tv.found) reinterpret_cast<float *>(pool.sh_c + slot)[3] = 1.0f; }
                 else pool.hit[slot] = make_uint4(tv.hit.pos, __float_as_uint(tv.hit.t), __float_as_uint(tv.hit.u), __float_as_uint(tv.hit.v));
                 have = false;
             }
             if (s_pos < s_n) {
                 const unsigned int idx = s_pos + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
+                bool began = false; uint32_t root_tested = 0;
                 if (tv.done() && idx < s_n) {
                     const float4 ro = st_o[wv][idx], rd = st_d[wv][idx]; slot = st_slot[wv][idx];
+                    if (KIND == TK_BOTH) { any = (slot >> 31) != 0u; slot &= 0x7fffffffu; }
                     Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
-                    n_rays++; have = true;
-                    tv.begin(sc, r, n_boxes);
+                    have = true; began = true;
+                    tv.begin(sc, r, root_tested);
                 }
+                n_boxes += (unsigned int) __popcll(__ballot(root_tested != 0u));
+                n_rays_any += (unsigned int) __popcll(__ballot(began && KIND == TK_BOTH && any));
+                n_rays += (unsigned int) __popcll(__ballot(began && !(KIND == TK_BOTH && any)));
                 s_pos += (unsigned int) __popcll(fin);
             }
             if (!loading && s_pos >= s_n && b_next >= n_batches && __ballot(have) == 0ull) break;   // nothing staged, loading or in flight
@@ -465,70 +480,98 @@ __global__ __launch_bounds__(256) void k_trace_pool(DevScene sc, Pool pool, unsi
         bool ran = false;
         if (m_in && (__popcll(m_in) >= thr.x || __ballot(tv.at_leaf()) == 0ull)) {
             if (PROF) { pf[1]++; pf[2] += __popcll(m_in); }
-            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, n_boxes); }
-            else if (tv.at_inner()) tv.box_step(nodes, stk, n_boxes);
+            n_boxes += 2u * (unsigned int) __popcll(m_in);
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy); }
+            else if (tv.at_inner()) tv.box_step(nodes, stk, dummy);
             ran = true;
         }
         const unsigned long long m_lf = __ballot(tv.at_leaf());
         if (m_lf && (__popcll(m_lf) >= thr.y || !ran)) {
             if (PROF) { pf[3]++; pf[4] += __popcll(m_lf); }
-            if (tv.at_leaf()) tv.prim_step(sc, n_prims);
+            n_prims += (unsigned int) __popcll(m_lf);
+            if (tv.at_leaf()) tv.prim_step(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
         }
         if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
         if (tv.at_pop()) tv.pop_step(stk);
     }
-    unsigned long long v[3] = {n_rays, n_boxes, n_prims};
-    for (int k = 0; k < 3; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
-    if (lane == 0 && (v[0] | v[1])) {
+    const unsigned long long v[4] = {n_rays, n_boxes, n_prims, n_rays_any};
+    if (lane == 0 && (v[0] | v[1] | v[3])) {
         DevStats *st = my_stats(stats);
         atomicAdd(ANY ? &st->shadow : &st->closest, v[0]); atomicAdd(&st->nodes, v[1]); atomicAdd(&st->prims, v[2]);
-        if (!ANY) { atomicAdd(&st->ext_rays, v[0]); atomicAdd(&st->ext_nodes, v[1]); atomicAdd(&st->ext_prims, v[2]); }
+        if (KIND == TK_BOTH) atomicAdd(&st->shadow, v[3]);
+        // the work of the kernel the roofline is quoted on (the extend stage, or the merged trace stage)
+        if (!ANY) { atomicAdd(&st->ext_rays, v[0] + v[3]); atomicAdd(&st->ext_nodes, v[1]); atomicAdd(&st->ext_prims, v[2]); }
         if (PROF) for (int k = 0; k < 10; ++k) atomicAdd(&st->prof[ANY ? 1 : 0][k], (unsigned long long) pf[k]);
     }
 }
 
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
-// stage launch per bounce would be mostly launch latency.  Each lane takes one surviving slot of the live list
-// (its closest hit and shadow result are already in the pool) and runs its path to the end.
+// stage launch per bounce would be mostly launch latency.  Persistent waves run the surviving paths of the live
+// list to their end, one bounce per loop trip (shade -> shadow -> extend in registers); wave w of W takes the
+// 64-entry batches w, w+W, ... and a lane whose path has ended takes the next entry of the wave's batch.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
     __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
     const unsigned int n = CN_LIVE(cnt);
-    LdsStack stk; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + (threadIdx.x & 63u);
+    const unsigned int lane = threadIdx.x & 63u;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, n_batches = (n + 63u) >> 6;
+    unsigned int batch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
+    unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
+    LdsStack stk; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
     Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned int slot = q_live[i];
-        float4 L = pool.li[slot];
-        unsigned int flags = __float_as_uint(L.w);
-        if (!(flags & PF_ACTIVE)) continue;
-        uint4 h = pool.hit[slot];
-        float4 P = pool.pix[slot];
-        PathState ps; ps.li = add_pending_nee(f3(L.x, L.y, L.z), flags, pool.sh_c[slot]);
-        if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
-            float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; uint4 R = pool.rng[slot];
-            ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
-            ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
-            Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
-            Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
-            for (;;) {
-                ShadeOut so;
-                shade_hit(sc, ps, rng, hit, so);
-                if (so.has_shadow) {
-                    Hit sh; ctr.shadow++;
-                    if (!trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
+    bool alive = false; unsigned int slot = 0;
+    PathState ps; Pcg32 rng; Hit hit; float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (batch >= n_batches) return;
+    for (;;) {
+        const unsigned long long dead = __ballot(!alive);
+        if (dead && batch < n_batches) {
+            const unsigned int idx = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) dead, 0u));
+            if (!alive && idx < end) {
+                slot = q_live[idx];
+                const float4 L = pool.li[slot];
+                const unsigned int flags = __float_as_uint(L.w);
+                if (flags & PF_ACTIVE) {
+                    const uint4 h = pool.hit[slot];
+                    P = pool.pix[slot];
+                    ps.li = add_pending_nee(f3(L.x, L.y, L.z), flags, pool.sh_c[slot]);
+                    if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
+                        const float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; const uint4 R = pool.rng[slot];
+                        ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
+                        ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
+                        rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
+                        hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
+                        alive = true;
+                    } else {
+                        const unsigned int pxy = __float_as_uint(P.z);
+                        if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
+                    }
+                    pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+                    pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f); pool.sh_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);
                 }
-                if (so.end) break;
-                ctr.closest++;
-                if (!trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims)) break;
+            }
+            cursor += (unsigned int) __popcll(dead);
+            if (cursor >= end) { batch += n_waves; cursor = batch << 6; end = (cursor + 64u < n) ? cursor + 64u : n; }
+        }
+        if (__ballot(alive) == 0ull) { if (batch >= n_batches) break; else continue; }
+        if (alive) {
+            // one bounce: the hit is in registers
+            ShadeOut so;
+            shade_hit(sc, ps, rng, hit, so);
+            if (so.has_shadow) {
+                Hit sh; ctr.shadow++;
+                if (!trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
+            }
+            bool go_on = !so.end;
+            if (go_on) { ctr.closest++; go_on = trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims); }
+            if (!go_on) {
+                const unsigned int pxy = __float_as_uint(P.z);
+                if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
+                alive = false;
             }
         }
-        unsigned int pxy = __float_as_uint(P.z);
-        if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
-        pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
-        pool.ray_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f); pool.sh_d[slot] = make_float4(0.f, 0.f, 0.f, -1.f);
     }
     unsigned long long v[5] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
     for (int k = 0; k < 5; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
-    if ((threadIdx.x & 63) == 0 && (v[0] | v[1] | v[2])) {
+    if (lane == 0 && (v[0] | v[1] | v[2])) {
         DevStats *st = my_stats(stats);
         atomicAdd(&st->closest, v[0]); atomicAdd(&st->shadow, v[1]); atomicAdd(&st->invalid, v[2]); atomicAdd(&st->nodes, v[3]); atomicAdd(&st->prims, v[4]);
     }
@@ -629,6 +672,7 @@ struct NoriHipContext {
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
+    bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_queue step thresholds (lanes)
     // adds the elapsed time of the recorded extend launches to ext_ms_acc (waits for them)
@@ -679,6 +723,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
     if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
+    if (const char *e = getenv("NORI_HIP_MERGE")) c->merge_trace = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_PROFILE")) c->profile = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
         int a, b, d; if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 1 && b >= 1 && d >= 1 && a <= 64 && b <= 64 && d <= 64) { c->thr_box = a; c->thr_prim = b; c->thr_refill = d; }
@@ -912,8 +957,8 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     int trace_bpc = ctx->trace_blocks_per_cu;
     if (trace_bpc == 0) {
         int occ_e = 0, occ_s = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, (const void *) k_trace_pool<false, false>, 256, 0));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, (const void *) k_trace_pool<true, false>, 256, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, (const void *) k_trace_pool<TK_BOTH, false>, 256, 0));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, (const void *) k_trace_pool<TK_SHADOW, false>, 256, 0));
         trace_bpc = std::max(1, std::min(occ_e, occ_s));
         if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage occupancy: %d / %d workgroups per CU\n", occ_e, occ_s);
     }
@@ -924,18 +969,23 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     for (;; ++it) {
         hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
         hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, job, ctx->d_film, ctx->d_qlive, ctx->d_flags, c, ctx->d_counter, ctx->d_stats);
-        if (ctx->profile) {
-            hipLaunchKernelGGL((k_trace_pool<true, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
-            hipLaunchKernelGGL((k_trace_pool<false, true>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
-        } else {
-            hipLaunchKernelGGL((k_trace_pool<true, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
+        {
             if (ctx->ext_used + 2 > ctx->ext_ev.size()) {
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
                 else { hipEvent_t a_, b_; HIPCHK(hipEventCreate(&a_)); HIPCHK(hipEventCreate(&b_)); ctx->ext_ev.push_back(a_); ctx->ext_ev.push_back(b_); }
             }
-            HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
-            hipLaunchKernelGGL((k_trace_pool<false, false>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr);
-            HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used + 1], ctx->stream));
+#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr)
+            if (ctx->merge_trace) {
+                HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
+                if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
+                HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used + 1], ctx->stream));
+            } else {
+                if (ctx->profile) ND_TRACE(TK_SHADOW, true); else ND_TRACE(TK_SHADOW, false);
+                HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
+                if (ctx->profile) ND_TRACE(TK_EXTEND, true); else ND_TRACE(TK_EXTEND, false);
+                HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used + 1], ctx->stream));
+            }
+#undef ND_TRACE
             ctx->ext_used += 2;
         }
         HIPCHK(hipGetLastError());
@@ -949,7 +999,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
             if (n_upper == 0) break;
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
-                hipLaunchKernelGGL(k_finish, dim3(std::max(1u, (n_upper + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film,
+                hipLaunchKernelGGL(k_finish, dim3(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u))), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film,
                                    (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
                 ++it;
