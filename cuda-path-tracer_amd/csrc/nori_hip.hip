@@ -266,8 +266,8 @@ __device__ __forceinline__ F3 add_pending_nee(F3 li, unsigned int flags, float4 
 //   pass B  starts new paths in the freed slots from the reserved work items (src/render.cpp:83-98) and writes the
 //           live list (used by the host for termination and by k_finish)
 enum { SF_REGEN = 1u, SF_KEEP = 2u, SF_IDLE = 4u };
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
-                                               unsigned int *flag_buf, WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
+__device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, const RenderJob &job, float4 *film, unsigned int *q_live,
+                                           unsigned int *flag_buf, WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
     __shared__ unsigned int w_tot[4][2];
     __shared__ unsigned long long b_work; __shared__ unsigned int b_live;
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -387,6 +387,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
     if (lane == 0 && (v0 | v1)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); }
 }
+// built for several register budgets (waves per SIMD); the stage is bound by the latency of its dependent fetches
+#define ND_SHADE_KERNEL(W) \
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) \
+void k_shade_w##W(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, unsigned int *flag_buf, WfCounters *cnt, \
+                  unsigned long long *work_counter, DevStats *stats) { shade_body(sc, pool, n_slots, job, film, q_live, flag_buf, cnt, work_counter, stats); }
+ND_SHADE_KERNEL(3)
+ND_SHADE_KERNEL(4)
+ND_SHADE_KERNEL(5)
+ND_SHADE_KERNEL(6)
+ND_SHADE_KERNEL(8)
 
 // Trace stage: persistent waves over the pool.  Wave w of W takes the 64-slot batches w, w+W, w+2W, ... (a static,
 // interleaved share: no shared counter).  Rays reach the lanes through a small pipeline, so that the HBM latency of
@@ -668,7 +678,8 @@ struct NoriHipContext {
     size_t ext_used = 0; double ext_ms_acc = 0.0; uint64_t ext_launches = 0;
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
     unsigned int finish_below = 0;    // live paths below which k_finish takes over; 0 = a quarter of the pool (NORI_HIP_FINISH)
-    int shade_blocks_per_cu = 6;      // k_shade: blocks per CU (each block owns one contiguous run of the queue)
+    int shade_waves = 4;              // k_shade variant: waves per SIMD (NORI_HIP_SHADE_WAVES = 3, 4, 5, 6 or 8)
+    int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
@@ -719,6 +730,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) c->pipeline = (std::string(e) == "mega") ? 0 : 1;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
+    if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
@@ -964,11 +976,14 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     }
     const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
     const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
+    const int SW = ctx->shade_waves;
+    void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, unsigned int *, WfCounters *, unsigned long long *, DevStats *) =
+        SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     uint64_t it = 0;
     for (;; ++it) {
         hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
-        hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, job, ctx->d_film, ctx->d_qlive, ctx->d_flags, c, ctx->d_counter, ctx->d_stats);
+        hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, job, ctx->d_film, ctx->d_qlive, ctx->d_flags, c, ctx->d_counter, ctx->d_stats);
         {
             if (ctx->ext_used + 2 > ctx->ext_ev.size()) {
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
