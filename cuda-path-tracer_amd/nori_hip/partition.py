@@ -30,7 +30,12 @@ def split_spp(total_spp, world):
 
 
 def allreduce_film(film, dist):
-    """sum the ranks' films in place (torch tensor, any device); a no-op without a process group"""
+    """sum the ranks' films in place (torch tensor, any device); a no-op without a process group.  The caller has
+    synchronised the render stream before (the collective runs on torch's stream and reads the film); on return the
+    collective has completed, so the render stream may clear or extend the film again."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(film)
+        if film.is_cuda:
+            import torch
+            torch.cuda.current_stream(film.device).synchronize()
     return film
