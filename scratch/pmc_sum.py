@@ -4,7 +4,7 @@ tot = collections.defaultdict(float)
 for f in sorted(glob.glob('gpurun_out/pmc_%s_*/*/*counter_collection.csv' % tag)):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        name = 'k_render' if 'k_render' in k else ('k_shade' if 'k_shade' in k else ('shadow' if 'k_trace_pool<true' in k else ('extend' if 'k_trace_pool<false' in k else ('finish' if 'k_finish' in k else None))))
+        name = 'k_render' if 'k_render' in k else ('k_shade' if 'k_shade' in k else ('shadow' if 'k_trace_pool<1' in k else ('trace' if 'k_trace_pool<2' in k else ('extend' if 'k_trace_pool<0' in k else ('finish' if 'k_finish' in k else None)))))
         if name: tot[(name, r['Counter_Name'])] += float(r['Counter_Value'])
 ks = sorted(set(k for k, _ in tot))
 for k in ks:
