@@ -9,6 +9,7 @@ over ranks with one RCCL all-reduce per step, inside the timed region.
 Workloads (BASELINE.json configs):
   table  scenes/table/table_path_mis_microfacet.xml 800x600, 256 spp   (configs[1]: the single-GPU configuration; default)
   cbox   scenes/cbox/cbox_path_mis.xml at 512x512, 64 spp      (configs[0], the reference's CPU-runnable case)
+  dragon scenes/proj/dragon-diffuse.xml 800x600, 64 spp        (mid-size: 105 k triangles, depth-26 tree)
   c4     synthetic ~10M-triangle height field under area lights, 1024x1024, 16 spp (config 4)
 """
 import argparse
@@ -69,6 +70,8 @@ WORKLOADS = {
                  name="cbox path_mis 512x512 64spp (BASELINE config 1 geometry, 10252 triangles)"),
     "table": dict(xml="scenes/table/table_path_mis_microfacet.xml", width=800, height=600, spp=256,
                   name="table path_mis microfacet+dielectric 800x600 256spp (BASELINE config 2)"),
+    "dragon": dict(xml="scenes/proj/dragon-diffuse.xml", width=800, height=600, spp=64,
+                   name="dragon-diffuse path_mis 800x600 64spp (scenes/proj, 105k triangles, mesh emitter)"),
     "c4": dict(xml=None, width=1024, height=1024, spp=16, n_side=2236,
                name="synthetic 10M-triangle height field under 4 area lights 1024x1024 16spp (BASELINE config 4)"),
 }

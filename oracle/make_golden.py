@@ -224,13 +224,22 @@ def main():
     assert np.array_equal(kat, O.pcg32(42, 54, 6))
     print("pcg32 KAT (ext/pcg32/pcg32-demo.out:8) ok for reference and oracle")
     S = os.path.join(ROOT, "scenes")
-    scene_fixture("cbox", S + "/cbox/cbox_path_mis.xml", 64, 64, 2048, 1)
-    scene_fixture("cbox_mirror_microfacet", S + "/cbox/cbox_mirror_microfacet.xml", 64, 64, 2048, 2)
-    scene_fixture("table", S + "/table/table_path_mis.xml", 64, 48, 2048, 3)
-    scene_fixture("table_microfacet", S + "/table/table_path_mis_microfacet.xml", 64, 48, 2048, 4)
-    test_scene_fixtures()
-    bsdf_fixture()
-    ttest_fixture()
+    only = sys.argv[1:]                      # fixture names to (re)generate; default all
+    scenes = [("cbox", S + "/cbox/cbox_path_mis.xml", 64, 64, 2048, 1),
+              ("cbox_mirror_microfacet", S + "/cbox/cbox_mirror_microfacet.xml", 64, 64, 2048, 2),
+              ("table", S + "/table/table_path_mis.xml", 64, 48, 2048, 3),
+              ("table_microfacet", S + "/table/table_path_mis_microfacet.xml", 64, 48, 2048, 4),
+              # 105 k triangles, depth-26 tree, a 960-triangle mesh emitter (CDF search) and an emitter of zero radiance
+              ("dragon", S + "/proj/dragon-diffuse.xml", 64, 48, 2048, 5)]
+    for sc in scenes:
+        if not only or sc[0] in only:
+            scene_fixture(*sc)
+    if not only or "test_scenes" in only:
+        test_scene_fixtures()
+    if not only or "bsdf" in only:
+        bsdf_fixture()
+    if not only or "ttest" in only:
+        ttest_fixture()
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ import nori_hip as NH
 import oracle_lib as O
 from conftest import ROOT, SCENES
 
-XMLS = ["cbox/cbox_path_mis.xml", "cbox/cbox_mirror_microfacet.xml", "table/table_path_mis.xml", "table/table_path_mis_microfacet.xml"]
+XMLS = ["cbox/cbox_path_mis.xml", "cbox/cbox_mirror_microfacet.xml", "table/table_path_mis.xml", "table/table_path_mis_microfacet.xml", "proj/dragon-diffuse.xml"]
 
 
 def test_c_abi_exports_every_declared_symbol():

@@ -14,6 +14,7 @@ SCENE_XML = {
     "cbox_mirror_microfacet": "cbox/cbox_mirror_microfacet.xml",
     "table": "table/table_path_mis.xml",
     "table_microfacet": "table/table_path_mis_microfacet.xml",
+    "dragon": "proj/dragon-diffuse.xml",
 }
 
 
