@@ -279,3 +279,32 @@ def test_single_triangle_scene_has_a_dummy_root(loaded):
     img = ctx.read_bitmap()
     assert img.max() == 2.0 and img.min() == 0.0                              # emitter seen directly, background black
     hs.close()
+
+
+def test_full_size_properties_of_the_bench_workload():
+    """BASELINE configs[1] at full size (800x600, 256 spp: 123 M camera samples, ~0.5 G rays), where the oracle is too
+    slow to compare images: size-independent properties of the film instead."""
+    W, H, spp = 800, 600, 256
+    hs = NH.HostScene(os.path.join(SCENES, SCENE_XML["table_microfacet"]), W, H, spp)
+    ctx = hs.preprocess()
+    ctx.reset_stats(); ctx.clear_film(); ctx.render(0, spp)
+    whole = ctx.read_film(); st = ctx.stats()
+    b = (whole.shape[0] - H) // 2
+    # every sample lands exactly once (ImageBlock::put adds weight 1 per valid sample)
+    assert st["camera_samples"] == W * H * spp
+    assert whole[:, :, 3].sum(dtype=np.float64) == W * H * spp - st["invalid_samples"]
+    assert st["invalid_samples"] < 1e-6 * W * H * spp
+    # the half-pixel shifted box of src/block.cpp:107-111: interior pixels receive exactly spp samples in expectation,
+    # the film is finite and non-negative
+    assert np.isfinite(whole).all() and (whole >= 0).all()
+    inner = whole[b + 2:b + H - 2, b + 2:b + W - 2, 3]
+    assert abs(inner.mean() - spp) < 0.01 * spp
+    # linearity in the sample range: two slices accumulate to the same film (fp32 atomics: order differs only)
+    ctx.clear_film(); ctx.render(0, 100); ctx.render(100, spp)
+    parts = ctx.read_film()
+    assert np.array_equal(parts[:, :, 3], whole[:, :, 3])
+    np.testing.assert_allclose(parts[:, :, :3], whole[:, :, :3], rtol=2e-4, atol=1e-3)
+    # ray accounting is deterministic
+    st2 = ctx.stats()
+    assert st2["closest_rays"] == 2 * st["closest_rays"] and st2["shadow_rays"] == 2 * st["shadow_rays"]
+    hs.close()
