@@ -418,10 +418,15 @@ ND_SHADE_KERNEL(8)
 // its ray), so an iteration has one kernel tail instead of two.
 enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 template <int KIND, bool PROF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr) {
-    __shared__ uint2 lds_stack[4 * TRACE_DEPTH * 64];
-    __shared__ float4 st_o[4][64], st_d[4][64];
-    __shared__ unsigned int st_slot[4][64];
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int n_cached) {
+    // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | slots | cached nodes
+    extern __shared__ float4 dyn_lds[];
+    const unsigned int nw = blockDim.x >> 6;
+    float4 *st_o_all = dyn_lds + nw * (TRACE_DEPTH * 64 * 8 / 16);
+    float4 *st_d_all = st_o_all + nw * 64;
+    unsigned int *st_slot_all = reinterpret_cast<unsigned int *>(st_d_all + nw * 64);
+    float4 *const st_o = st_o_all + (threadIdx.x >> 6) * 64, *const st_d = st_d_all + (threadIdx.x >> 6) * 64;
+    unsigned int *const st_slot = st_slot_all + (threadIdx.x >> 6) * 64;
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     constexpr bool ANY = (KIND == TK_SHADOW);
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, nb_pool = (n_slots + 63u) >> 6, n_batches = (KIND == TK_BOTH) ? 2u * nb_pool : nb_pool;
@@ -429,8 +434,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
     bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
-    LdsStackT<TRACE_DEPTH> stk; stk.base = (lds_u64 *) lds_stack + wv * (TRACE_DEPTH * 64) + lane;
-    GlobalNodes nodes; nodes.nodes = sc.nodes;
+    LdsStackT<TRACE_DEPTH> stk; stk.base = (lds_u64 *) dyn_lds + wv * (TRACE_DEPTH * 64) + lane;
+    CachedNodes nodes; nodes.nodes = sc.nodes; nodes.n = n_cached;
+    nodes.cache = (lds_f4 *) (reinterpret_cast<float4 *>(st_slot_all + nw * 64));
+    if (n_cached) { nodes.fill(); __syncthreads(); }
     bool any = ANY;                                                      // this lane's ray is a shadow ray
     bool l_any = ANY;                                                    // wave-uniform: kind of the batch in flight
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
             const unsigned long long m = __ballot(valid);
             if (valid) {
                 const unsigned int r = __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
-                st_o[wv][r] = lo4; st_d[wv][r] = ld4; st_slot[wv][r] = (l_base + lane) | ((KIND == TK_BOTH && l_any) ? 0x80000000u : 0u);
+                st_o[r] = lo4; st_d[r] = ld4; st_slot[r] = (l_base + lane) | ((KIND == TK_BOTH && l_any) ? 0x80000000u : 0u);
             }
             s_n = (unsigned int) __popcll(m); s_pos = 0; loading = false;
         }
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void k
                 const unsigned int idx = s_pos + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
                 bool began = false; uint32_t root_tested = 0;
                 if (tv.done() && idx < s_n) {
-                    const float4 ro = st_o[wv][idx], rd = st_d[wv][idx]; slot = st_slot[wv][idx];
+                    const float4 ro = st_o[idx], rd = st_d[idx]; slot = st_slot[idx];
                     if (KIND == TK_BOTH) { any = (slot >> 31) != 0u; slot &= 0x7fffffffu; }
                     Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
                     have = true; began = true;
@@ -683,6 +690,8 @@ struct NoriHipContext {
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
+    int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
+    bool trace_cache = false;         // NORI_HIP_TRACE_CACHE=1: keep the top of the tree in the trace workgroups' spare LDS (no gain measured)
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_queue step thresholds (lanes)
@@ -735,6 +744,8 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
     if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
+    if (const char *e = getenv("NORI_HIP_TRACE_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) c->trace_threads = v; }
+    if (const char *e = getenv("NORI_HIP_TRACE_CACHE")) c->trace_cache = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_MERGE")) c->merge_trace = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_PROFILE")) c->profile = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
@@ -965,16 +976,24 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
     const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
     const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : P / 4, P);
-    // the trace stages give every wave a static share of the pool, so all their workgroups must be resident at once
+    // the trace stages give every wave a static share of the pool, so all their workgroups must be resident at once.
+    // LDS of a workgroup: stacks + staging buffers of its waves, the rest of its share caches the top of the tree.
+    const unsigned trace_threads = (unsigned) ctx->trace_threads, trace_nw = trace_threads / 64;
+    const size_t trace_fixed = (size_t) trace_nw * (TRACE_DEPTH * 64 * 8 + 64 * 36);
     int trace_bpc = ctx->trace_blocks_per_cu;
-    if (trace_bpc == 0) {
-        int occ_e = 0, occ_s = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_e, (const void *) k_trace_pool<TK_BOTH, false>, 256, 0));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_s, (const void *) k_trace_pool<TK_SHADOW, false>, 256, 0));
-        trace_bpc = std::max(1, std::min(occ_e, occ_s));
-        if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage occupancy: %d / %d workgroups per CU\n", occ_e, occ_s);
-    }
-    const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
+    if (trace_bpc == 0) trace_bpc = std::max(1, std::min<int>((int) (6 * 4 / trace_nw), (int) (163840 / trace_fixed)));      // 6 waves per SIMD (80 VGPRs)
+    const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_bpc)) & ~(size_t) 255;
+    if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
+    const unsigned int trace_cached = ctx->trace_cache ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((trace_share - trace_fixed) / 64)) : 0u;
+    const size_t trace_lds = trace_fixed + (size_t) trace_cached * 64;
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, %u nodes cached\n", trace_threads, trace_bpc, trace_lds, trace_cached);
+    const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + trace_threads - 1) / trace_threads, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
     const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
     const int SW = ctx->shade_waves;
     void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, unsigned int *, WfCounters *, unsigned long long *, DevStats *) =
@@ -989,7 +1008,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
                 else { hipEvent_t a_, b_; HIPCHK(hipEventCreate(&a_)); HIPCHK(hipEventCreate(&b_)); ctx->ext_ev.push_back(a_); ctx->ext_ev.push_back(b_); }
             }
-#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr)
+#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr, trace_cached)
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
                 if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
