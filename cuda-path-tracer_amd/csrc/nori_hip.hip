@@ -615,9 +615,16 @@ __global__ void k_srgb(const float *rgb, size_t n, float *out) {
 #define NLM_BW 16
 #define NLM_BH 16
 __global__ __launch_bounds__(NLM_BW * NLM_BH) void k_nlmeans(const float *img, float *out, int w, int h, int r, int f, float sigma, float hh) {
-    extern __shared__ float lds[];          // (NLM_BH + 2R) x (NLM_BW + 2R) x 3, R = r + f
+    extern __shared__ float lds[];          // (NLM_BH + 2R) x (NLM_BW + 2R) x 3, R = r + f; then the (2f+1)^2 patch weights
     const int R = r + f;
     const int tw = NLM_BW + 2 * R, th = NLM_BH + 2 * R;
+    // the patch weight exp(-(k^2+l^2)/(2 sigma^2)) (cuda/filter.cc.cu:77) depends on the tap only: one table per block
+    float *wtab = lds + 3 * tw * th;
+    const int pw = 2 * f + 1;
+    for (int i = threadIdx.y * NLM_BW + threadIdx.x; i < pw * pw; i += NLM_BW * NLM_BH) {
+        int k = i / pw - f, l = i % pw - f;
+        wtab[i] = expf(-(float) (k * k + l * l) / (2.0f * sigma * sigma));
+    }
     const int bx = blockIdx.x * NLM_BW, by = blockIdx.y * NLM_BH;
     for (int i = threadIdx.y * NLM_BW + threadIdx.x; i < tw * th; i += NLM_BW * NLM_BH) {
         int ly = i / tw, lx = i % tw;
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(NLM_BW * NLM_BH) void k_nlmeans(const float *img, f
     __syncthreads();
     const int x = bx + threadIdx.x, y = by + threadIdx.y;
     if (x >= w || y >= h) return;
-    const float sigma2 = sigma * sigma, h2 = hh * hh;
+    const float h2 = hh * hh;
     const int minX = max(0, x - r), maxX = min(w - 1, x + r), minY = max(0, y - r), maxY = min(h - 1, y + r);
     float wsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int i = minX; i <= maxX; ++i) for (int j = minY; j <= maxY; ++j) {
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(NLM_BW * NLM_BH) void k_nlmeans(const float *img, f
         for (int k = pminx; k <= pmaxx; ++k) for (int l = pminy; l <= pmaxy; ++l) {
             const float *p = &lds[3 * ((y + l - by + R) * tw + (x + k - bx + R))];
             const float *q = &lds[3 * ((j + l - by + R) * tw + (i + k - bx + R))];
-            float wk = expf(-(float) (k * k + l * l) / (2.0f * sigma2));
+            float wk = wtab[(k + f) * pw + (l + f)];
             float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
             float patchv = (dx * dx + dy * dy + dz * dz) / h2;
             d2 += wk * patchv;
@@ -652,6 +659,73 @@ __global__ __launch_bounds__(NLM_BW * NLM_BH) void k_nlmeans(const float *img, f
     }
     float *o = out + ((size_t) y * w + x) * 3;
     o[0] = a0 / wsum; o[1] = a1 / wsum; o[2] = a2 / wsum;
+}
+
+// The same filter with the patch distance evaluated separably.  The tap weight factors, exp(-(k^2+l^2)/(2 sigma^2)) =
+// g(k) g(l), and the clipped patch ranges of the reference (both pixels inside the image) are the same as summing a
+// squared-difference image that is zero where either pixel is outside.  Per window offset the block builds that
+// image for its tile (+f border), filters it horizontally, and every lane finishes its pixel with a vertical pass:
+// (2f+1) + (2f+1) taps per pixel and offset instead of (2f+1)^2.  Sums are grouped differently from the direct
+// kernel, so results agree to rounding (tests: rtol 2e-4), not bit for bit; NORI_HIP_FILTER=direct selects k_nlmeans.
+__global__ __launch_bounds__(NLM_BW * NLM_BH) void k_nlmeans_sep(const float *img, float *out, int w, int h, int r, int f, float sigma, float hh) {
+    extern __shared__ float lds[];
+    const int R = r + f;
+    const int tw = NLM_BW + 2 * R, th = NLM_BH + 2 * R;          // image tile
+    const int dw = NLM_BW + 2 * f, dh = NLM_BH + 2 * f;          // squared-difference tile
+    float *tile = lds;                                           // th x tw x 3
+    float *D = tile + 3 * tw * th;                               // dh x dw
+    float *Hb = D + dw * dh;                                     // dh x NLM_BW
+    float *g = Hb + dh * NLM_BW;                                 // 2f+1
+    const int bx = blockIdx.x * NLM_BW, by = blockIdx.y * NLM_BH;
+    const int tid = threadIdx.y * NLM_BW + threadIdx.x, nt = NLM_BW * NLM_BH;
+    for (int i = tid; i < tw * th; i += nt) {
+        int ly = i / tw, lx = i % tw;
+        int gx = bx + lx - R, gy = by + ly - R;
+        float a = 0.f, b = 0.f, c = 0.f;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) { const float *p = img + ((size_t) gy * w + gx) * 3; a = p[0]; b = p[1]; c = p[2]; }
+        tile[3 * i] = a; tile[3 * i + 1] = b; tile[3 * i + 2] = c;
+    }
+    for (int i = tid; i <= 2 * f; i += nt) { int k = i - f; g[i] = expf(-(float) (k * k) / (2.0f * sigma * sigma)); }
+    const int x = bx + threadIdx.x, y = by + threadIdx.y;
+    const bool inside = x < w && y < h;
+    const float h2 = hh * hh;
+    float wsum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int di = -r; di <= r; ++di) for (int dj = -r; dj <= r; ++dj) {
+        __syncthreads();                                         // tile/g ready; previous offset's Hb consumed
+        for (int i = tid; i < dw * dh; i += nt) {
+            int v = i / dw, u = i % dw;
+            int px = bx - f + u, py = by - f + v, qx = px + di, qy = py + dj;
+            float d = 0.f;
+            if (px >= 0 && px < w && py >= 0 && py < h && qx >= 0 && qx < w && qy >= 0 && qy < h) {
+                const float *p = &tile[3 * ((py - by + R) * tw + (px - bx + R))];
+                const float *q = &tile[3 * ((qy - by + R) * tw + (qx - bx + R))];
+                float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+                d = (dx * dx + dy * dy + dz * dz) / h2;
+            }
+            D[i] = d;
+        }
+        __syncthreads();
+        for (int i = tid; i < NLM_BW * dh; i += nt) {
+            int v = i / NLM_BW, xx = i % NLM_BW;
+            float acc = 0.f;
+            for (int k = 0; k <= 2 * f; ++k) acc += g[k] * D[v * dw + xx + k];
+            Hb[i] = acc;
+        }
+        __syncthreads();
+        const int qx = x + di, qy = y + dj;
+        if (inside && qx >= 0 && qx < w && qy >= 0 && qy < h) {
+            float d2 = 0.f;
+            for (int l = 0; l <= 2 * f; ++l) d2 += g[l] * Hb[(threadIdx.y + l) * NLM_BW + threadIdx.x];
+            int pminx = max(max(-f, -x), -qx), pmaxx = min(min(f, w - x - 1), w - qx - 1);
+            int pminy = max(max(-f, -y), -qy), pmaxy = min(min(f, h - y - 1), h - qy - 1);
+            d2 /= (float) ((pmaxx - pminx + 1) * (pmaxy - pminy + 1));
+            float wgt = expf(-fmaxf(d2, 0.0f));
+            wsum += wgt;
+            const float *c = &tile[3 * ((qy - by + R) * tw + (qx - bx + R))];
+            a0 += wgt * c[0]; a1 += wgt * c[1]; a2 += wgt * c[2];
+        }
+    }
+    if (inside) { float *o = out + ((size_t) y * w + x) * 3; o[0] = a0 / wsum; o[1] = a1 / wsum; o[2] = a2 / wsum; }
 }
 
 template <typename T> int upload(T *&dptr, const T *src, size_t n) {
@@ -1095,17 +1169,26 @@ int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, flo
     if (!out) return fail(NORI_HIP_EINVAL, "null buffer");
     if (r < 0 || f < 0 || !(sigma > 0) || !(h > 0)) return fail(NORI_HIP_EINVAL, "bad filter parameters");
     const int W = ctx->sc.cam.width, H = ctx->sc.cam.height, R = r + f;
-    size_t lds = (size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 * sizeof(float);
+    size_t lds = ((size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 + (size_t) (2 * f + 1) * (2 * f + 1)) * sizeof(float);
     if (lds > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile (r + f <= 48)");
     size_t n = (size_t) W * H * 3;
     float *d_lin = nullptr, *d_srgb = nullptr, *d_out = nullptr;
     HIPCHK(hipMalloc((void **) &d_lin, n * 4)); HIPCHK(hipMalloc((void **) &d_srgb, n * 4)); HIPCHK(hipMalloc((void **) &d_out, n * 4));
     hipLaunchKernelGGL(k_bitmap, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d_lin);
     hipLaunchKernelGGL(k_srgb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float *) d_lin, n, d_srgb);
+    const char *fenv = getenv("NORI_HIP_FILTER");
+    const bool direct = fenv && std::string(fenv) == "direct";
+    const size_t lds_sep = ((size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 + (size_t) (NLM_BW + 2 * f) * (NLM_BH + 2 * f) + (size_t) (NLM_BH + 2 * f) * NLM_BW + (size_t) (2 * f + 1)) * sizeof(float);
+    if (!direct && lds_sep > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile");
     HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans_sep, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_sep));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_nlmeans, dim3((W + NLM_BW - 1) / NLM_BW, (H + NLM_BH - 1) / NLM_BH), dim3(NLM_BW, NLM_BH), lds, ctx->stream,
-                       (const float *) d_srgb, d_out, W, H, r, f, sigma, h);
+    if (direct)
+        hipLaunchKernelGGL(k_nlmeans, dim3((W + NLM_BW - 1) / NLM_BW, (H + NLM_BH - 1) / NLM_BH), dim3(NLM_BW, NLM_BH), lds, ctx->stream,
+                           (const float *) d_srgb, d_out, W, H, r, f, sigma, h);
+    else
+        hipLaunchKernelGGL(k_nlmeans_sep, dim3((W + NLM_BW - 1) / NLM_BW, (H + NLM_BH - 1) / NLM_BH), dim3(NLM_BW, NLM_BH), lds_sep, ctx->stream,
+                           (const float *) d_srgb, d_out, W, H, r, f, sigma, h);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));

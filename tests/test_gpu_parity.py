@@ -165,14 +165,22 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
 
 
 def test_filter_pass_matches_oracle(loaded):
+    """both NL-means kernels (separable patch distance: default; direct sum: NORI_HIP_FILTER=direct) against the oracle's
+    restatement of cuda/filter.cc.cu:53-110, including windows and patches clipped at the image border"""
     W, H = 48, 40
     hs, ctx = loaded("cbox", W, H)
     ctx.clear_film(); ctx.render(0, 4)
     img = ctx.read_bitmap()
-    out = ctx.filter(r=3, f=4, sigma=0.5, h=0.45)
     srgb = np.where(img <= 0.0031308, 12.92 * img, 1.055 * np.power(np.maximum(img, 1e-12), 1 / 2.4) - 0.055).astype(np.float32)
-    ref = O.nl_means(srgb, 3, 4, 0.5, 0.45)
-    assert np.allclose(out, ref, rtol=2e-4, atol=2e-5)
+    for (r, f, sigma, h) in [(3, 4, 0.5, 0.45), (2, 10, 3.0, 0.8), (3, 10, 0.5, 0.002)]:
+        ref = O.nl_means(srgb, r, f, sigma, h)
+        for mode in ("sep", "direct"):
+            os.environ["NORI_HIP_FILTER"] = mode
+            try:
+                out = ctx.filter(r=r, f=f, sigma=sigma, h=h)
+            finally:
+                del os.environ["NORI_HIP_FILTER"]
+            assert np.allclose(out, ref, rtol=2e-4, atol=2e-5), (mode, r, f, sigma, h, np.abs(out - ref).max())
 
 
 def test_error_behaviour(loaded):
