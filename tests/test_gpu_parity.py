@@ -132,7 +132,7 @@ def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
     assert np.allclose(parts, whole, rtol=1e-4, atol=1e-5)                    # fp32 atomics: order differs, values do not
 
 
-@pytest.mark.parametrize("name", ["cbox_mirror_microfacet", "table"])
+@pytest.mark.parametrize("name", ["cbox_mirror_microfacet", "table", "dragon"])
 def test_wavefront_and_single_kernel_pipelines_agree(name):
     """The staged pipeline (shade / shadow / extend kernels over a slot pool) and the single persistent kernel run the
     same per-sample arithmetic; only the fp32 atomic summation order into the film differs.  A small slot pool forces
