@@ -91,6 +91,8 @@ struct DevScene {
     const float *cdf;
     const NoriHipShadePrim *light_prims;
     uint32_t root, n_emitters;
+    int ordered;                       // 0: the reference's child order (left first; decides ties, bit-exact hits).  1: nearer child first —
+                                       // fewer box tests, same hit except where two primitives tie within rounding (NORI_HIP_ORDER=near)
     int prim_lanes;                    // run-to-completion traversal: lanes that must wait at a leaf before a record step is issued
     uint32_t n_top;                    // nodes [0, n_top) are the top of the tree in breadth-first order (LDS cache candidates)
     float root_min[3], root_max[3];
@@ -205,7 +207,7 @@ template <bool ANY> struct Trav {
     // bbox.h:345-358) return exactly min/max of their operands; its per-axis "nearT > farT" exits are implied by the
     // final comparison because nearT only grows and farT only shrinks.  Same decisions and entry distances (up to
     // the sign of a zero, which no comparison sees), a third of the instructions.
-    template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step_fast(const NodesT &nodes, StackT &stk, uint32_t &n_boxes) {
+    template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step_fast(const NodesT &nodes, StackT &stk, uint32_t &n_boxes, const bool ordered = false) {
         float4 n0, n1, n2, n3; nodes.fetch(cur, n0, n1, n2, n3);
         uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
         n_boxes += 2;
@@ -221,10 +223,11 @@ template <bool ANY> struct Trav {
         float fr = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(bx1, bx2), __builtin_fmaxf(by1, by2)), __builtin_fmaxf(bz1, bz2));
         bool hl = (nl <= fl) & (mint <= fl) & (nl <= maxt);
         bool hr = (nrr <= fr) & (mint <= fr) & (nrr <= maxt) & (right != NORI_HIP_NO_CHILD);
-        if (hl & hr) stk.push(sp++, make_uint2(right, __float_as_uint(nrr)));
-        cur = hl ? left : (hr ? right : ND_POP);
+        const bool sw = ordered & hl & hr & (nrr < nl);                  // ordered mode: the right child is entered first
+        if (hl & hr) stk.push(sp++, make_uint2(sw ? left : right, __float_as_uint(sw ? nl : nrr)));
+        cur = hl ? (sw ? right : left) : (hr ? right : ND_POP);
     }
-    template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step(const NodesT &nodes, StackT &stk, uint32_t &n_boxes) {
+    template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step(const NodesT &nodes, StackT &stk, uint32_t &n_boxes, const bool ordered = false) {
         float4 n0, n1, n2, n3; nodes.fetch(cur, n0, n1, n2, n3);
         float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
         float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
@@ -233,8 +236,9 @@ template <bool ANY> struct Trav {
         n_boxes += 2;
         bool hl = slab(lmin, lmax, o, d, rcp, mint, maxt, nl);
         bool hr = slab(rmin, rmax, o, d, rcp, mint, maxt, nrr) & (right != NORI_HIP_NO_CHILD);
-        if (hl & hr) stk.push(sp++, make_uint2(right, __float_as_uint(nrr)));
-        cur = hl ? left : (hr ? right : ND_POP);
+        const bool sw = ordered & hl & hr & (nrr < nl);
+        if (hl & hr) stk.push(sp++, make_uint2(sw ? left : right, __float_as_uint(sw ? nl : nrr)));
+        cur = hl ? (sw ? right : left) : (hr ? right : ND_POP);
     }
     // one record of the current leaf; afterwards the lane is at the next record, in ND_POP (leaf finished) or done
     __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) { prim_step(sc, n_prims, ANY); }
@@ -295,12 +299,15 @@ template <bool ANY> struct Trav {
 template <bool ANY, typename StackT, typename NodesT>
 __device__ __forceinline__ bool trace(const DevScene &sc, const NodesT &nodes, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
     Trav<ANY> tv;
+    // any-hit: maxt never shrinks, so the set of records reached and with it the answer is the same for every child
+    // order; the nearer child first finds an occluder sooner.  closest-hit: the reference's order unless sc.ordered
+    const bool ordered = ANY || sc.ordered != 0;
     tv.begin(sc, ray_in, n_nodes);
     for (;;) {
         const unsigned long long m_in = __ballot(tv.at_inner());
         if (m_in) {
-            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, n_nodes); }
-            else if (tv.at_inner()) { if (tv.special) tv.box_step(nodes, stk, n_nodes); else tv.box_step_fast(nodes, stk, n_nodes); }
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, n_nodes, ordered); }
+            else if (tv.at_inner()) { if (tv.special) tv.box_step(nodes, stk, n_nodes, ordered); else tv.box_step_fast(nodes, stk, n_nodes, ordered); }
         }
         const unsigned long long m_lf = __ballot(tv.at_leaf());
         if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) { if (tv.at_leaf()) tv.prim_step(sc, n_prims); }

@@ -498,8 +498,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         if (m_in && (__popcll(m_in) >= thr.x || __ballot(tv.at_leaf()) == 0ull)) {
             if (PROF) { pf[1]++; pf[2] += __popcll(m_in); }
             n_boxes += 2u * (unsigned int) __popcll(m_in);
-            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy); }
-            else if (tv.at_inner()) tv.box_step(nodes, stk, dummy);
+            // shadow rays take the nearer child first (any child order gives the same any-hit answer), extend rays
+            // the reference's order unless sc.ordered
+            const bool ord = ((KIND == TK_BOTH) ? any : ANY) || (sc.ordered != 0 && true);
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
+            else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
             ran = true;
         }
         const unsigned long long m_lf = __ballot(tv.at_leaf());
@@ -763,6 +766,7 @@ struct NoriHipContext {
     int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
+    bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
     bool trace_cache = false;         // NORI_HIP_TRACE_CACHE=1: keep the top of the tree in the trace workgroups' spare LDS (no gain measured)
@@ -817,6 +821,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
+    if (const char *e = getenv("NORI_HIP_ORDER")) c->ordered = std::string(e) == "near";
     if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) c->trace_threads = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_CACHE")) c->trace_cache = atoi(e) != 0;
@@ -920,7 +925,7 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     DevScene &sc = ctx->sc;
     sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
-    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes;
+    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = ctx->ordered ? 1 : 0;
     for (int i = 0; i < 3; ++i) { sc.root_min[i] = d->root_min[i]; sc.root_max[i] = d->root_max[i]; }
     sc.cam = d->camera;
     sc.inv_w = 1.0f / (float) d->camera.width; sc.inv_h = 1.0f / (float) d->camera.height;
