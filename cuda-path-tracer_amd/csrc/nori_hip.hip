@@ -1061,7 +1061,8 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     const size_t trace_fixed = (size_t) trace_nw * (TRACE_DEPTH * 64 * 8 + 64 * 36);
     int trace_bpc = ctx->trace_blocks_per_cu;
     if (trace_bpc == 0) trace_bpc = std::max(1, std::min<int>((int) (6 * 4 / trace_nw), (int) (163840 / trace_fixed)));      // 6 waves per SIMD (80 VGPRs)
-    const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_bpc)) & ~(size_t) 255;
+    const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (6 * 4 / trace_nw)));     // more workgroups than that run in rounds
+    const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
     const unsigned int trace_cached = ctx->trace_cache ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((trace_share - trace_fixed) / 64)) : 0u;
     const size_t trace_lds = trace_fixed + (size_t) trace_cached * 64;
