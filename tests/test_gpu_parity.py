@@ -316,3 +316,23 @@ def test_full_size_properties_of_the_bench_workload():
     st2 = ctx.stats()
     assert st2["closest_rays"] == 2 * st["closest_rays"] and st2["shadow_rays"] == 2 * st["shadow_rays"]
     hs.close()
+
+
+def test_baseline_config0_image_against_oracle_and_the_reference_binary(loaded):
+    """BASELINE configs[0] as a whole: cbox 512x512 at 64 spp through the render pipeline.  The oracle renders the same
+    sample indices (same per-sample streams), so the two images are the same estimate; the reference binary's own
+    render of this configuration (different streams) had mean RGB 0.150194 / 0.116927 / 0.125327."""
+    W = H = 512; spp = 64
+    hs, ctx = loaded("cbox", W, H)
+    ctx.clear_film(); ctx.reset_stats(); ctx.render(0, spp)
+    img = ctx.read_bitmap(); st = ctx.stats()
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML["cbox"]), W, H, spp)
+    _, ost = o.render(0, spp, mode=1, threads=16)
+    oimg = o.bitmap()
+    gm, om = img.mean((0, 1)), oimg.mean((0, 1))
+    assert np.all(np.abs(gm - om) / om < 1e-3), (gm, om)                      # north_star: mean relative error <= 1e-3
+    assert np.all(np.abs(gm - [0.150194, 0.116927, 0.125327]) < 1.5e-3), gm   # Monte-Carlo noise of two 64-spp renders
+    close = np.abs(img - oimg).max(2) <= 1e-3 + 1e-2 * oimg.max(2)
+    assert close.mean() > 0.95, close.mean()
+    assert st["camera_samples"] == W * H * spp
+    assert abs(st["closest_rays"] - ost["closest"]) < 2e-3 * ost["closest"] and abs(st["shadow_rays"] - ost["shadow"]) < 2e-3 * ost["shadow"]
