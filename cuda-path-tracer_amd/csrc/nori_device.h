@@ -335,9 +335,11 @@ struct ScratchStack {
 // touch 64 consecutive 8-byte words, conflict-free for ds_read/write_b64) and the rare deeper entries in scratch.
 #define LDS_DEPTH 12
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+// (the spill array is a separate object, handed in by pointer: as a member it drags the whole struct, the LDS base
+// included, into scratch memory, and every push and pop then starts with a scratch load of that base)
 template <int DEPTH> struct LdsStackT {
     lds_u64 *base;                      // this lane's column: base[entry * 64] (LDS address space, so ds_read/ds_write)
-    uint2 spill[ND_STACK - DEPTH];
+    uint2 *spill;                       // ND_STACK - DEPTH entries of private memory for the deeper levels
     __device__ __forceinline__ void push(int i, uint2 v) { if (i < DEPTH) base[i * 64] = ((unsigned long long) v.y << 32) | v.x; else spill[i - DEPTH] = v; }
     __device__ __forceinline__ uint2 pop(int i) const {
         if (i < DEPTH) { unsigned long long w = base[i * 64]; return make_uint2((unsigned int) w, (unsigned int) (w >> 32)); }

@@ -136,7 +136,8 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
 #define MEGA_DEPTH 8
 __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob &job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     extern __shared__ float4 dyn_lds[];
-    LdsStackT<MEGA_DEPTH> stk; stk.base = (lds_u64 *) dyn_lds + (threadIdx.x >> 6) * (MEGA_DEPTH * 64) + (threadIdx.x & 63u);
+    uint2 stack_spill[ND_STACK - MEGA_DEPTH];
+    LdsStackT<MEGA_DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + (threadIdx.x >> 6) * (MEGA_DEPTH * 64) + (threadIdx.x & 63u);
     CachedNodes nodes; nodes.nodes = sc.nodes; nodes.n = n_cached;
     nodes.cache = (lds_f4 *) dyn_lds + (MEGA_THREADS / 64) * (MEGA_DEPTH * 64 * 8 / 16);
     nodes.fill();
@@ -434,10 +435,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
-    LdsStackT<TRACE_DEPTH> stk; stk.base = (lds_u64 *) dyn_lds + wv * (TRACE_DEPTH * 64) + lane;
-    CachedNodes nodes; nodes.nodes = sc.nodes; nodes.n = n_cached;
-    nodes.cache = (lds_f4 *) (reinterpret_cast<float4 *>(st_slot_all + nw * 64));
-    if (n_cached) { nodes.fill(); __syncthreads(); }
+    uint2 stack_spill[ND_STACK - TRACE_DEPTH];
+    LdsStackT<TRACE_DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + wv * (TRACE_DEPTH * 64) + lane;
+    // (an LDS copy of the top of the tree, CachedNodes, was measured here: no gain, and a branch per node visit)
+    GlobalNodes nodes; nodes.nodes = sc.nodes; (void) n_cached;
     bool any = ANY;                                                      // this lane's ray is a shadow ray
     bool l_any = ANY;                                                    // wave-uniform: kind of the batch in flight
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
@@ -536,7 +537,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, n_batches = (n + 63u) >> 6;
     unsigned int batch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
     unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
-    LdsStack stk; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
+    uint2 stack_spill[ND_STACK - LDS_DEPTH];
+    LdsStack stk; stk.spill = stack_spill; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
     Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
     bool alive = false; unsigned int slot = 0;
     PathState ps; Pcg32 rng; Hit hit; float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -769,7 +771,7 @@ struct NoriHipContext {
     bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
-    bool trace_cache = false;         // NORI_HIP_TRACE_CACHE=1: keep the top of the tree in the trace workgroups' spare LDS (no gain measured)
+    bool trace_cache = false;         // (unused: the trace stage no longer caches nodes in LDS; kept so the environment knob parses)
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_queue step thresholds (lanes)
