@@ -448,6 +448,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     uint32_t dummy = 0;
     unsigned int pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};               // PROF only: wave-uniform step statistics
     for (;;) {
+        // (wave-uniform by construction; said explicitly so that they live in scalar registers and branch on SCC)
+        s_pos = __builtin_amdgcn_readfirstlane(s_pos); s_n = __builtin_amdgcn_readfirstlane(s_n);
+        b_next = __builtin_amdgcn_readfirstlane(b_next); l_base = __builtin_amdgcn_readfirstlane(l_base);
         // ---- feed the staging pipeline
         if (s_pos >= s_n && loading) {
             const bool valid = !(ld4.w < lo4.w);
