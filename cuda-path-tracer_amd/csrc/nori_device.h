@@ -90,6 +90,8 @@ struct DevScene {
     const NoriHipEmitter *emitters;
     const float *cdf;
     const NoriHipShadePrim *light_prims;
+    const NoriHipTexture *textures;    // image tables (null when the scene has none)
+    const uint8_t *tex_data;
     uint32_t root, n_emitters;
     int ordered;                       // 0: the reference's child order (left first; decides ties, bit-exact hits).  1: nearer child first —
                                        // fewer box tests, same hit except where two primitives tie within rounding (NORI_HIP_ORDER=near)
@@ -209,6 +211,11 @@ template <bool ANY> struct Trav {
     // the sign of a zero, which no comparison sees), a third of the instructions.
     template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step_fast(const NodesT &nodes, StackT &stk, uint32_t &n_boxes, const bool ordered = false) {
         float4 n0, n1, n2, n3; nodes.fetch(cur, n0, n1, n2, n3);
+        box_compute_fast(n0, n1, n2, n3, stk, n_boxes, ordered);
+    }
+    // the arithmetic of box_step_fast on a node that has been fetched already (kernels that issue the node and the
+    // record fetches of a trip together, before either is used)
+    template <typename StackT> __device__ __forceinline__ void box_compute_fast(const float4 n0, const float4 n1, const float4 n2, const float4 n3, StackT &stk, uint32_t &n_boxes, const bool ordered) {
         uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
         n_boxes += 2;
         float ax1 = (n0.x - o.x) * rcp.x, ax2 = (n0.w - o.x) * rcp.x;
@@ -229,6 +236,9 @@ template <bool ANY> struct Trav {
     }
     template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step(const NodesT &nodes, StackT &stk, uint32_t &n_boxes, const bool ordered = false) {
         float4 n0, n1, n2, n3; nodes.fetch(cur, n0, n1, n2, n3);
+        box_compute(n0, n1, n2, n3, stk, n_boxes, ordered);
+    }
+    template <typename StackT> __device__ __forceinline__ void box_compute(const float4 n0, const float4 n1, const float4 n2, const float4 n3, StackT &stk, uint32_t &n_boxes, const bool ordered) {
         float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
         float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
         uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
@@ -244,9 +254,15 @@ template <bool ANY> struct Trav {
     __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) { prim_step(sc, n_prims, ANY); }
     // `any`: stop at the first hit (a per-lane flag where one kernel traces shadow and extend rays together)
     __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims, const bool any) {
+        float4 A, B, C; prim_fetch(sc, A, B, C);
+        prim_compute(A, B, C, n_prims, any);
+    }
+    __device__ __forceinline__ void prim_fetch(const DevScene &sc, float4 &A, float4 &B, float4 &C) const {
+        const float4 *r = sc.prims + 3 * (size_t) (cur & 0x7fffffffu);
+        A = r[0]; B = r[1]; C = r[2];
+    }
+    __device__ __forceinline__ void prim_compute(const float4 A, const float4 B, const float4 C, uint32_t &n_prims, const bool any) {
         const uint32_t pos = cur & 0x7fffffffu;
-        const float4 *r = sc.prims + 3 * (size_t) pos;
-        float4 A = r[0], B = r[1], C = r[2];
         const uint32_t flags = __float_as_uint(C.z);
         n_prims++;
         float t, u, v; bool h;
@@ -354,7 +370,66 @@ typedef LdsStackT<LDS_DEPTH> LdsStack;
 
 struct Surface { F3 p; F2 uv; Frame sh; F3 geo_n; uint32_t shape; uint32_t prim; };
 
-// Mesh::setHitInformation (src/mesh.cpp:123-168) / Sphere::setHitInformation (src/sphere.cpp:115-141)
+// ---- images (cuda/nori/imagetexture.cpp.cu:12-26, bumpMap.cpp.cu:10-27, normalMap.cpp.cu:10-24; src/imagetexture.cpp:49-77)
+// rescale, shift, keep the fractional part
+__device__ __forceinline__ F2 tex_coords(const NoriHipTexture &t, F2 uv) {
+    float x = (uv.x / t.scale[0]) - t.delta[0], y = (uv.y / t.scale[1]) - t.delta[1];
+    return f2(x - floorf(x), y - floorf(y));
+}
+// One filtered lookup of the 4-byte texels as four floats; `cu` runs along the columns, `rv` along the rows, both in
+// [0, 1).  BILINEAR restates tex2D of the CUDA fork's texture objects (normalised coordinates, wrap addressing, linear
+// filter: texel centres at i + 0.5, blend weights held with 8 fractional bits); NEAREST is the CPU renderer's
+// truncating lookup.  `dec` turns a texel word into four floats.
+template <typename Dec>
+__device__ __forceinline__ float4 tex_lookup(const DevScene &sc, const NoriHipTexture &t, float cu, float rv, Dec dec) {
+    const uint32_t *tx = reinterpret_cast<const uint32_t *>(sc.tex_data + t.offset);
+    const int W = (int) t.width, H = (int) t.height;
+    if (t.lookup == NORI_HIP_LOOKUP_NEAREST) {
+        int col = (int) (cu * (float) W), row = (int) (rv * (float) H);
+        col = col < W ? col : W - 1; row = row < H ? row : H - 1;
+        return dec(tx[(size_t) row * W + col]);
+    }
+    float xb = cu * (float) W - 0.5f, yb = rv * (float) H - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float a = floorf((xb - fi) * 256.0f + 0.5f) * (1.0f / 256.0f), b = floorf((yb - fj) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i0 = (int) fi, j0 = (int) fj;
+    i0 = i0 < 0 ? i0 + W : i0; j0 = j0 < 0 ? j0 + H : j0;
+    int i1 = i0 + 1 == W ? 0 : i0 + 1, j1 = j0 + 1 == H ? 0 : j0 + 1;
+    float4 t00 = dec(tx[(size_t) j0 * W + i0]), t10 = dec(tx[(size_t) j0 * W + i1]), t01 = dec(tx[(size_t) j1 * W + i0]), t11 = dec(tx[(size_t) j1 * W + i1]);
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return make_float4(((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x, ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
+                       ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z, ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w);
+}
+struct DecRgba8 { __device__ __forceinline__ float4 operator()(uint32_t w) const {      // cudaReadModeNormalizedFloat of uchar4
+    return make_float4((float) (w & 0xffu) / 255.0f, (float) ((w >> 8) & 0xffu) / 255.0f, (float) ((w >> 16) & 0xffu) / 255.0f, (float) (w >> 24) / 255.0f); } };
+struct DecS16x2 { __device__ __forceinline__ float4 operator()(uint32_t w) const {      // ... of short: v / 32767, clamped at -1
+    float x = (float) (int16_t) (w & 0xffffu) / 32767.0f, y = (float) (int16_t) (w >> 16) / 32767.0f;
+    return make_float4(x < -1.0f ? -1.0f : x, y < -1.0f ? -1.0f : y, 0.f, 0.f); } };
+// Color3f::toLinearRGB (src/common.cpp:208-222)
+__device__ __forceinline__ float srgb_to_linear(float v) { return v <= 0.04045f ? v * (1.0f / 12.92f) : powf((v + 0.055f) * (1.0f / 1.055f), 2.4f); }
+// ImageTexture<Color3f>::eval
+__device__ __forceinline__ F3 tex_color(const DevScene &sc, const NoriHipTexture &t, F2 uv) {
+    F2 c = tex_coords(t, uv);
+    float4 rgb = tex_lookup(sc, t, c.y, c.x, DecRgba8());                  // tex2D(image_tex, y, x) / row = x*rows, col = y*cols
+    if (t.lookup == NORI_HIP_LOOKUP_NEAREST) return f3(rgb.x, rgb.y, rgb.z);
+    return f3(srgb_to_linear(rgb.x), srgb_to_linear(rgb.y), srgb_to_linear(rgb.z));
+}
+// BumpMap::eval / NormalMap::eval: the new shading normal
+__device__ __forceinline__ F3 tex_normal(const DevScene &sc, const NoriHipTexture &t, F2 uv, const Frame &fr) {
+    F2 c = tex_coords(t, uv);
+    if (t.kind == NORI_HIP_TEX_BUMP) {
+        float4 g = tex_lookup(sc, t, c.x, c.y, DecS16x2());                // tex2D(image_tex_x / _y, x, y)
+        F3 n = (fr.n + g.x * cross(fr.n, fr.s)) - g.y * cross(fr.n, fr.t);
+        return normalized(n);
+    }
+    float4 rgb = tex_lookup(sc, t, c.y, c.x, DecRgba8());
+    F3 n = normalized(f3((2.0f * rgb.x) - 1.0f, (2.0f * rgb.y) - 1.0f, rgb.z));
+    return fr.toWorld(n);
+}
+
+// Mesh::setHitInformation (src/mesh.cpp:123-168) / Sphere::setHitInformation (src/sphere.cpp:115-141); EXT adds the
+// CUDA fork's normal modifier (cuda/nori/mesh.cpp.cu:181-185, sphere.cpp.cu:145-149)
+template <bool EXT = false>
 __device__ __forceinline__ void surface_from_hit(const DevScene &sc, const Ray &ray, const Hit &hit, Surface &s, bool want_geo) {
     const float4 *r = sc.prims + 3 * (size_t) hit.pos;
     float4 C = r[2];
@@ -372,22 +447,23 @@ __device__ __forceinline__ void surface_from_hit(const DevScene &sc, const Ray &
         float theta = acosf(frac) / ND_PI;
         float phi = (atan2f(pl.y, pl.x) + ND_PI) / (2 * ND_PI);
         s.uv = f2(phi, theta);
-        return;
-    }
-    const NoriHipShadePrim &sp = sc.shade[hit.pos];
-    float b0 = 1 - (hit.u + hit.v), b1 = hit.u, b2 = hit.v;
-    F3 p0 = f3(sp.p0), p1 = f3(sp.p1), p2 = f3(sp.p2);
-    s.p = (b0 * p0 + b1 * p1) + b2 * p2;
-    if (shp.flags & 2u) s.uv = f2((b0 * sp.uv0[0] + b1 * sp.uv1[0]) + b2 * sp.uv2[0], (b0 * sp.uv0[1] + b1 * sp.uv1[1]) + b2 * sp.uv2[1]);
-    else s.uv = f2(hit.u, hit.v);
-    if (shp.flags & 1u) {
-        F3 n = normalized_seq((b0 * f3(sp.n0) + b1 * f3(sp.n1)) + b2 * f3(sp.n2));
-        s.sh.set(n);
-        if (want_geo) s.geo_n = normalized(cross(p1 - p0, p2 - p0));
     } else {
-        F3 g = normalized(cross(p1 - p0, p2 - p0));
-        s.sh.set(g); s.geo_n = g;
+        const NoriHipShadePrim &sp = sc.shade[hit.pos];
+        float b0 = 1 - (hit.u + hit.v), b1 = hit.u, b2 = hit.v;
+        F3 p0 = f3(sp.p0), p1 = f3(sp.p1), p2 = f3(sp.p2);
+        s.p = (b0 * p0 + b1 * p1) + b2 * p2;
+        if (shp.flags & 2u) s.uv = f2((b0 * sp.uv0[0] + b1 * sp.uv1[0]) + b2 * sp.uv2[0], (b0 * sp.uv0[1] + b1 * sp.uv1[1]) + b2 * sp.uv2[1]);
+        else s.uv = f2(hit.u, hit.v);
+        if (shp.flags & 1u) {
+            F3 n = normalized_seq((b0 * f3(sp.n0) + b1 * f3(sp.n1)) + b2 * f3(sp.n2));
+            s.sh.set(n);
+            if (want_geo) s.geo_n = normalized(cross(p1 - p0, p2 - p0));
+        } else {
+            F3 g = normalized(cross(p1 - p0, p2 - p0));
+            s.sh.set(g); s.geo_n = g;
+        }
     }
+    if (EXT && shp.normal_tex) { F3 n = tex_normal(sc, sc.textures[shp.normal_tex - 1], s.uv, s.sh); s.sh.set(n); }
 }
 
 // PerspectiveCamera::sampleRay (src/perspective.cpp:90-111); Transform::operator* (include/nori/transform.h:68-81)
@@ -460,25 +536,34 @@ __device__ __forceinline__ float smith_g1(float alpha, F3 v, F3 m) {      // src
     float a2 = a * a;
     return (3.535f * a + 2.181f * a2) / (1.0f + 2.276f * a + 2.577f * a2);
 }
-__device__ __forceinline__ F3 bsdf_eval(const NoriHipShape &b, F3 wi, F3 wo) {
+// Subsurface::fresnelTransmission (src/subsurface.cpp:173-178)
+__device__ __forceinline__ float ss_fresnel_transmission(const NoriHipShape &b, F3 wi, F3 wo) {
+    float Ft_i = 1.0f - fresnel(wi.z, b.ext_ior, b.int_ior);
+    float Ft_o = 1.0f - fresnel(wo.z, b.ext_ior, b.int_ior);
+    return Ft_i * Ft_o;
+}
+// `alb`: the albedo at the hit's uv (constant colour or image; diffuse albedo | microfacet kd | subsurface albedo)
+__device__ __forceinline__ F3 bsdf_eval(const NoriHipShape &b, F3 alb, F3 wi, F3 wo) {
     if (b.bsdf == NORI_HIP_BSDF_DIFFUSE) {                                // src/diffuse.cpp:75-86
         if (wi.z <= 0 || wo.z <= 0) return f3(0.f);
-        return f3(b.albedo) * ND_INV_PI;
+        return alb * ND_INV_PI;
     }
+    if (b.bsdf == NORI_HIP_BSDF_SUBSURFACE)                               // src/subsurface.cpp:99-104 (no hemisphere test)
+        return (ss_fresnel_transmission(b, wi, wo) * alb) * ND_INV_PI;
     if (b.bsdf == NORI_HIP_BSDF_MICROFACET) {                             // src/microfacet.cpp:87-100
         F3 wh = normalized(wi + wo);
         float G = smith_g1(b.alpha, wi, wh) * smith_g1(b.alpha, wo, wh);
         float ci = wi.z, co = wo.z;
         if (co > 0 && ci > 0) {
             float spec = (b.ks * beckmann_D(b.alpha, wh) * fresnel(dot(wh, wi), b.ext_ior, b.int_ior) * G) / (4 * ci * co);
-            return f3(b.albedo) / ND_PI + f3(spec);
+            return alb / ND_PI + f3(spec);
         }
         return f3(0.f);
     }
     return f3(0.f);
 }
 __device__ __forceinline__ float bsdf_pdf(const NoriHipShape &b, F3 wi, F3 wo) {
-    if (b.bsdf == NORI_HIP_BSDF_DIFFUSE) {                                // src/diffuse.cpp:89-105
+    if (b.bsdf == NORI_HIP_BSDF_DIFFUSE || b.bsdf == NORI_HIP_BSDF_SUBSURFACE) {   // src/diffuse.cpp:89-105, src/subsurface.cpp:181-197
         if (wi.z <= 0 || wo.z <= 0) return 0.0f;
         return ND_INV_PI * wo.z;
     }
@@ -492,13 +577,18 @@ __device__ __forceinline__ float bsdf_pdf(const NoriHipShape &b, F3 wi, F3 wo) {
     return 0.0f;
 }
 // returns the importance weight; wo_valid=false marks the reference's early returns that leave wo unset
-__device__ __forceinline__ F3 bsdf_sample(const NoriHipShape &b, F3 wi, F2 sample, F3 &wo, bool &is_delta, bool &wo_valid) {
+// (`sample2` is the second of the two samples the integrator hands over; only the subsurface model uses it)
+__device__ __forceinline__ F3 bsdf_sample(const NoriHipShape &b, F3 alb, F3 wi, F2 sample, F2 sample2, F3 &wo, bool &is_delta, bool &wo_valid) {
     wo_valid = true; is_delta = false; wo = f3(0.f);
     switch (b.bsdf) {
     case NORI_HIP_BSDF_DIFFUSE:                                           // src/diffuse.cpp:109-126
         if (wi.z <= 0) { wo_valid = false; return f3(0.f); }
         wo = square_to_cosine_hemisphere(sample);
-        return f3(b.albedo);
+        return alb;
+    case NORI_HIP_BSDF_SUBSURFACE:                                        // src/subsurface.cpp:253-281
+        wo = square_to_cosine_hemisphere(sample2);
+        if (wi.z <= 0 || wo.z <= 0) return f3(0.f);
+        return ss_fresnel_transmission(b, wi, wo) * alb;
     case NORI_HIP_BSDF_MICROFACET: {                                      // src/microfacet.cpp:121-161
         if (sample.x < b.ks) {
             sample.x /= b.ks;
@@ -513,7 +603,7 @@ __device__ __forceinline__ F3 bsdf_sample(const NoriHipShape &b, F3 wi, F2 sampl
         float co = wo.z;
         if (co > 0) {
             float pdf_val = bsdf_pdf(b, wi, wo);
-            if (fabsf(pdf_val) > 1e-6) return (bsdf_eval(b, wi, wo) * co) / pdf_val;
+            if (fabsf(pdf_val) > 1e-6) return (bsdf_eval(b, alb, wi, wo) * co) / pdf_val;
         }
         return f3(0.f);
     }
@@ -594,20 +684,63 @@ struct PathState {
 __device__ __forceinline__ void path_init(PathState &ps, const Ray &r) {
     ps.ray = r; ps.t = f3(1.0f); ps.li = f3(0.f); ps.last_bsdf_pdf = 1.0f; ps.last_delta = true;
 }
-struct Counters { uint32_t closest, shadow, nodes, prims; };
-
 // What the shading of one hit leaves behind for the shadow stage
 struct ShadeOut { bool end; bool has_shadow; Ray shadow; F3 contrib; };
+
+// ---- subsurface: where the path leaves the object (src/subsurface.cpp:106-150,199-249, src/pathMisIntegrator.cpp:86-100)
+__device__ __forceinline__ float ss_cdf(float r, float cs, float cd) {
+    float rsd = -r * cs / cd;
+    return (1.0f - 0.25f * expf(rsd)) - 0.75f * expf(rsd / 3.0f);
+}
+__device__ __forceinline__ float ss_cdf_derivative(float r, float cs, float cd) {
+    float sd = cs / cd, rsd = -r * sd;
+    return (sd * 0.25f) * (expf(rsd) + expf(rsd / 3.0f));
+}
+// Subsurface::diffuseScatterPDFsample: radius by three Newton steps on the CDF, uniform angle
+__device__ __forceinline__ F2 ss_sample_disk(F2 s2, float cs, float cd) {
+    float sample = s2.x, sdInv = cd / cs;
+    float r0 = (float) (((-log((double) (1.0f - sample) * 4.0 / 3.0)) * (double) 3.0f) * (double) sdInv);
+    for (int i = 0; i < 3; ++i) {
+        float f = ss_cdf(r0, cs, cd) - sample, df = ss_cdf_derivative(r0, cs, cd);
+        r0 = r0 - f / df;
+    }
+    float theta = 2.0f * ND_PI * s2.y;
+    float sn, c; sincosf(theta, &sn, &c);
+    return f2(r0 * c, r0 * sn);
+}
+// a closest-hit query that only sees the records of shape `mask` (BVH::rayIntersect's `mask` argument, src/bvh.cpp:404,438),
+// run to completion by one lane with a private stack
+__device__ __forceinline__ bool trace_masked(const DevScene &sc, const Ray &ray, uint32_t mask, Hit &hit, uint32_t &n_nodes, uint32_t &n_prims) {
+    ScratchStack stk; GlobalNodes nodes; nodes.nodes = sc.nodes;
+    Trav<false> tv; tv.begin(sc, ray, n_nodes);
+    while (!tv.done()) {
+        if (tv.at_inner()) { if (tv.special) tv.box_step(nodes, stk, n_nodes, sc.ordered != 0); else tv.box_step_fast(nodes, stk, n_nodes, sc.ordered != 0); }
+        else if (tv.at_leaf()) {
+            float4 A, B, C; tv.prim_fetch(sc, A, B, C);
+            const uint32_t fl = __float_as_uint(C.z);
+            if ((fl & 0xffffffu) == mask) tv.prim_compute(A, B, C, n_prims, false);
+            else tv.cur = (fl & 0x80000000u) ? ND_POP : (NORI_HIP_LEAF_BIT | ((tv.cur & 0x7fffffffu) + 1u));
+        } else tv.pop_step(stk);
+    }
+    hit = tv.hit;
+    return tv.found;
+}
+#define ND_PROBE_TRIES 4096      /* the reference retries without bound; a path that never finds its way out is dropped here */
+
+struct Counters { uint32_t closest, shadow, nodes, prims; };
 
 // The part of one bounce between the closest-hit query and the shadow query (src/pathMisIntegrator.cpp:42-164):
 // emission with the MIS weight of the previous BSDF sample, Russian roulette, BSDF sampling, emitter sampling.
 // Updates ps (radiance so far, throughput, next ray, last pdf); out.contrib is what the NEE adds if the shadow ray
 // is unoccluded.  out.end: the path stops after this bounce (roulette, or a zero BSDF weight — the reference keeps
 // bouncing with zero throughput, which adds exact zeros).
-__device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg32 &rng, const Hit &hit, ShadeOut &out) {
+// EXT: scenes with images (albedo textures, bump / normal maps) or subsurface shapes; the probe rays of the latter
+// are traced here, by the shading lane (`ctr`, if given, counts them as closest-hit rays).
+template <bool EXT = false>
+__device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg32 &rng, const Hit &hit, ShadeOut &out, Counters *ctr = nullptr) {
     out.end = false; out.has_shadow = false; out.contrib = f3(0.f);
     Surface sf;
-    surface_from_hit(sc, ps.ray, hit, sf, false);
+    surface_from_hit<EXT>(sc, ps.ray, hit, sf, false);
     const NoriHipShape &shp = sc.shapes[sf.shape];
     if (shp.emitter >= 0) {                                               // :42-63
         const NoriHipEmitter &em = sc.emitters[shp.emitter];
@@ -623,12 +756,32 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
     ps.t = ps.t / successProb;
 
     F3 wi_l = sf.sh.toLocal(-ps.ray.d);                                   // :81-109
-    F2 s2 = rng.next2D(); F2 s1 = rng.next2D(); (void) s2;                // second argument is drawn first
+    F3 alb = f3(shp.albedo);
+    if (EXT && shp.albedo_tex) alb = tex_color(sc, sc.textures[shp.albedo_tex - 1], sf.uv);
+    // its_out: where the path continues from.  The hit itself, except for subsurface shapes (:86-100)
+    F3 op = sf.p; Frame osh = sf.sh;
+    if (EXT && shp.bsdf == NORI_HIP_BSDF_SUBSURFACE) {
+        bool found = false;
+        for (int tries = 0; tries < ND_PROBE_TRIES && !found; ++tries) {  // Subsurface::sampleDx, src/subsurface.cpp:199-249
+            float thres = rng.next1D();
+            F3 d = thres < 0.5f ? -sf.sh.n : thres < 0.625f ? sf.sh.t : thres < 0.75f ? -sf.sh.t : thres < 0.875f ? sf.sh.s : -sf.sh.s;
+            F2 dx = ss_sample_disk(rng.next2D(), shp.ss_cs, shp.ss_cd);
+            Frame fr; fr.set(-d);
+            Ray probe; probe.d = d; probe.o = sf.p + fr.toWorld(f3(dx.x, dx.y, 0.f));
+            probe.mint = -1e-3f; probe.maxt = nd_sqrt(dx.x * dx.x + dx.y * dx.y) + 1e-3f;
+            Hit ph; uint32_t nn = 0, np = 0;
+            found = trace_masked(sc, probe, sf.shape, ph, nn, np);
+            if (ctr) { ctr->closest++; ctr->nodes += nn; ctr->prims += np; }
+            if (found) { Surface so; surface_from_hit<EXT>(sc, probe, ph, so, false); op = so.p; osh = so.sh; }
+        }
+        if (!found) { out.end = true; return; }
+    }
+    F2 s2 = rng.next2D(); F2 s1 = rng.next2D();                           // second argument is drawn first
     F3 wo; bool is_delta, wo_valid;
-    F3 f = bsdf_sample(shp, wi_l, s1, wo, is_delta, wo_valid);
+    F3 f = bsdf_sample(shp, alb, wi_l, s1, s2, wo, is_delta, wo_valid);
     ps.last_bsdf_pdf = wo_valid ? bsdf_pdf(shp, wi_l, wo) : 0.0f;
     ps.last_delta = is_delta;
-    F3 next_dir = wo_valid ? normalized(sf.sh.toWorld(wo)) : f3(0.f);
+    F3 next_dir = wo_valid ? normalized(osh.toWorld(wo)) : f3(0.f);
 
     float pick = rng.next1D();                                            // :114 (drawn for delta BSDFs too)
     if (!is_delta) {
@@ -636,28 +789,28 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
         uint32_t index = (uint32_t) floorf((float) n * pick); if (index > n - 1) index = n - 1;
         const NoriHipEmitter &em = sc.emitters[index];
         F3 lwi, ln, lp;
-        F3 liLoc = emitter_sample(sc, em, sf.p, rng.next2D(), lwi, ln, lp, out.shadow);
+        F3 liLoc = emitter_sample(sc, em, op, rng.next2D(), lwi, ln, lp, out.shadow);
         out.has_shadow = true;
-        F3 wo_l = sf.sh.toLocal(lwi);
+        F3 wo_l = osh.toLocal(lwi);
         float bpdf = bsdf_pdf(shp, wi_l, wo_l);
-        float lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), sf.p, lp, ln, lwi);
+        float lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), op, lp, ln, lwi);
         float wem = lpdf / (lpdf + bpdf);
-        float cosS = dot(normalized(lwi), normalized(sf.sh.n));
-        if (wem > 0) out.contrib = ((((ps.t * wem) * liLoc) * bsdf_eval(shp, wi_l, wo_l)) * fabsf(cosS)) * (float) n;
+        float cosS = dot(normalized(lwi), normalized(osh.n));
+        if (wem > 0) out.contrib = ((((ps.t * wem) * liLoc) * bsdf_eval(shp, alb, wi_l, wo_l)) * fabsf(cosS)) * (float) n;
     }
     if (!wo_valid || is_zero(f)) { out.end = true; return; }
-    ps.ray.d = next_dir; ps.ray.o = sf.p; ps.ray.mint = 1e-3f; ps.ray.maxt = ND_INF;
+    ps.ray.d = next_dir; ps.ray.o = op; ps.ray.mint = 1e-3f; ps.ray.maxt = ND_INF;
     ps.t = ps.t * f;
 }
 
 // One iteration of the reference's bounce loop, run to completion by one lane.  Returns false when the path ended.
-template <typename StackT, typename NodesT>
+template <bool EXT = false, typename StackT, typename NodesT>
 __device__ __forceinline__ bool path_bounce(const DevScene &sc, const NodesT &nodes, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     Hit hit;
     ctr.closest++;
     if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
     ShadeOut so;
-    shade_hit(sc, ps, rng, hit, so);
+    shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
     if (so.has_shadow) {
         Hit sh_hit;
         ctr.shadow++;
@@ -665,10 +818,10 @@ __device__ __forceinline__ bool path_bounce(const DevScene &sc, const NodesT &no
     }
     return !so.end;
 }
-template <typename StackT>
+template <bool EXT = false, typename StackT>
 __device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     GlobalNodes g; g.nodes = sc.nodes;
-    return path_bounce(sc, g, ps, rng, stk, ctr);
+    return path_bounce<EXT>(sc, g, ps, rng, stk, ctr);
 }
 
 } // namespace nd

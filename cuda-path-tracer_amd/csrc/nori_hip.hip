@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *ra
     }
     bool found = trace<false>(sc, ray, hit, stk, nn, np);
     if (found) {
-        Surface sf; surface_from_hit(sc, ray, hit, sf, true);
+        Surface sf; surface_from_hit<true>(sc, ray, hit, sf, true);
         out.prim = sf.prim; out.t = hit.t; out.u = sf.uv.x; out.v = sf.uv.y;
         if (full) {
             float *f = full + 16 * i;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void k_camera_rays(DevScene sc, const float *p
     rays[i] = o;
 }
 
+template <bool EXT>
 __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const int32_t *px, const int32_t *py, const uint64_t *states,
                                                     const uint64_t *seqs, const NoriHipRay *rays, float *rgb) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const
     else camera_ray(sc, f2(j.x * (float) sc.cam.width, j.y * (float) sc.cam.height), ray);      // src/ttest.cpp:171-172
     PathState ps; path_init(ps, ray);
     ScratchStack stk; Counters c = {0, 0, 0, 0};
-    while (path_bounce(sc, ps, rng, stk, c)) { }
+    while (path_bounce<EXT>(sc, ps, rng, stk, c)) { }
     rgb[3 * i] = ps.li.x; rgb[3 * i + 1] = ps.li.y; rgb[3 * i + 2] = ps.li.z;
 }
 
@@ -134,6 +135,7 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
 // fetch per trip), so it is built for several register budgets (waves per SIMD) and the host picks one.
 #define MEGA_THREADS 256
 #define MEGA_DEPTH 8
+template <bool EXT>
 __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob &job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     extern __shared__ float4 dyn_lds[];
     uint2 stack_spill[ND_STACK - MEGA_DEPTH];
@@ -180,7 +182,7 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
         }
         if (__ballot(alive) == 0ull) { if (exhausted && cursor >= end) break; else continue; }
         if (alive) {
-            if (!path_bounce(sc, nodes, ps, rng, stk, ctr)) {
+            if (!path_bounce<EXT>(sc, nodes, ps, rng, stk, ctr)) {
                 if (!film_put(sc, film, pixel_sample, px, py, ps.li)) n_invalid++;
                 alive = false;
             }
@@ -202,12 +204,15 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
 #define ND_RENDER_KERNEL(W) \
 __global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(W, W))) \
 void k_render_w##W(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) { \
-    render_body(sc, job, film, work_counter, stats, n_cached); }
+    render_body<false>(sc, job, film, work_counter, stats, n_cached); }
 ND_RENDER_KERNEL(3)
 ND_RENDER_KERNEL(4)
 ND_RENDER_KERNEL(5)
 ND_RENDER_KERNEL(6)
 ND_RENDER_KERNEL(8)
+// scenes with images or subsurface shapes (DevScene::textures / NORI_HIP_BSDF_SUBSURFACE): one register budget
+__global__ __launch_bounds__(MEGA_THREADS) void k_render_ext(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
+    render_body<true>(sc, job, film, work_counter, stats, n_cached); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Wavefront pipeline: the bounce loop of PathMisIntegrator::Li cut into stages that run as separate kernels over
@@ -267,6 +272,7 @@ __device__ __forceinline__ F3 add_pending_nee(F3 li, unsigned int flags, float4 
 //   pass B  starts new paths in the freed slots from the reserved work items (src/render.cpp:83-98) and writes the
 //           live list (used by the host for termination and by k_finish)
 enum { SF_REGEN = 1u, SF_KEEP = 2u, SF_IDLE = 4u };
+template <bool EXT>
 __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, const RenderJob &job, float4 *film, unsigned int *q_live,
                                            unsigned int *flag_buf, WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
     __shared__ unsigned int w_tot[4][2];
@@ -277,6 +283,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
     const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
     unsigned int c_regen = 0, c_keep = 0, n_invalid = 0;                    // the first two are wave-uniform
+    Counters probe_ctr = {0, 0, 0, 0};                                      // EXT: probe rays traced while shading
     const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
     for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
         const unsigned int slot = i0 + lane;
@@ -296,7 +303,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                     Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
                     Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
                     ShadeOut so;
-                    shade_hit(sc, ps, rng, hit, so);
+                    shade_hit<EXT>(sc, ps, rng, hit, so, EXT ? &probe_ctr : nullptr);
                     flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
                     if (so.has_shadow) {
                         new_shadow = true; flags |= PF_SHADOW;
@@ -387,17 +394,25 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     unsigned long long v0 = n_samples, v1 = n_invalid;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
     if (lane == 0 && (v0 | v1)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); }
+    if (EXT) {
+        unsigned long long w[3] = {probe_ctr.closest, probe_ctr.nodes, probe_ctr.prims};
+        for (int k = 0; k < 3; ++k) for (int off = 32; off > 0; off >>= 1) w[k] += __shfl_down(w[k], off, 64);
+        if (lane == 0 && w[0]) { DevStats *st = my_stats(stats); atomicAdd(&st->closest, w[0]); atomicAdd(&st->nodes, w[1]); atomicAdd(&st->prims, w[2]); }
+    }
 }
 // built for several register budgets (waves per SIMD); the stage is bound by the latency of its dependent fetches
 #define ND_SHADE_KERNEL(W) \
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) \
 void k_shade_w##W(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, unsigned int *flag_buf, WfCounters *cnt, \
-                  unsigned long long *work_counter, DevStats *stats) { shade_body(sc, pool, n_slots, job, film, q_live, flag_buf, cnt, work_counter, stats); }
+                  unsigned long long *work_counter, DevStats *stats) { shade_body<false>(sc, pool, n_slots, job, film, q_live, flag_buf, cnt, work_counter, stats); }
 ND_SHADE_KERNEL(3)
 ND_SHADE_KERNEL(4)
 ND_SHADE_KERNEL(5)
 ND_SHADE_KERNEL(6)
 ND_SHADE_KERNEL(8)
+__global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, unsigned int *flag_buf,
+                                                   WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
+    shade_body<true>(sc, pool, n_slots, job, film, q_live, flag_buf, cnt, work_counter, stats); }
 
 // Trace stage: persistent waves over the pool.  Wave w of W takes the 64-slot batches w, w+W, w+2W, ... (a static,
 // interleaved share: no shared counter).  Rays reach the lanes through a small pipeline, so that the HBM latency of
@@ -533,6 +548,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
 // stage launch per bounce would be mostly launch latency.  Persistent waves run the surviving paths of the live
 // list to their end, one bounce per loop trip (shade -> shadow -> extend in registers); wave w of W takes the
 // 64-entry batches w, w+W, ... and a lane whose path has ended takes the next entry of the wave's batch.
+template <bool EXT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
     __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
     const unsigned int n = CN_LIVE(cnt);
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (alive) {
             // one bounce: the hit is in registers
             ShadeOut so;
-            shade_hit(sc, ps, rng, hit, so);
+            shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
             if (so.has_shadow) {
                 Hit sh; ctr.shadow++;
                 if (!trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
@@ -753,6 +769,8 @@ struct NoriHipContext {
     DevScene sc;
     NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
+    NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
+    bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
     float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
     unsigned long long *d_counter = nullptr; DevStats *d_stats = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -790,6 +808,7 @@ struct NoriHipContext {
     }
     void free_scene() {
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
+        hipFree(d_textures); hipFree(d_tex_data); d_textures = nullptr; d_tex_data = nullptr; ext = false;
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
         have_scene = false;
     }
@@ -880,10 +899,24 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     if (!(d->prims[d->n_prims - 1].shape_flags & 0x80000000u)) return fail(NORI_HIP_EINVAL, "last primitive record does not end a leaf");
     for (uint32_t i = 0; i < d->n_prims; ++i)
         if ((d->prims[i].shape_flags & 0xffffffu) >= d->n_shapes) return fail(NORI_HIP_EINVAL, "primitive record " + std::to_string(i) + " names a shape out of range");
+    bool ext = false;
     for (uint32_t i = 0; i < d->n_shapes; ++i) {
         const NoriHipShape &s = d->shapes[i];
         if (s.emitter >= (int32_t) d->n_emitters) return fail(NORI_HIP_EINVAL, "shape emitter index out of range");
-        if (s.bsdf < 0 || s.bsdf > NORI_HIP_BSDF_MIRROR) return fail(NORI_HIP_EINVAL, "unknown BSDF kind");
+        if (s.bsdf < 0 || s.bsdf > NORI_HIP_BSDF_SUBSURFACE) return fail(NORI_HIP_EINVAL, "unknown BSDF kind");
+        if (s.bsdf == NORI_HIP_BSDF_SUBSURFACE) { ext = true; if (!(s.ss_cs > 0.f) || !(s.ss_cd > 0.f)) return fail(NORI_HIP_EINVAL, "subsurface shape without ss_cs / ss_cd"); }
+        if (s.albedo_tex > d->n_textures || s.normal_tex > d->n_textures) return fail(NORI_HIP_EINVAL, "shape names a texture out of range");
+        if (s.albedo_tex && d->textures[s.albedo_tex - 1].kind != NORI_HIP_TEX_COLOR) return fail(NORI_HIP_EINVAL, "albedo texture is not a colour image");
+        if (s.normal_tex && d->textures[s.normal_tex - 1].kind == NORI_HIP_TEX_COLOR) return fail(NORI_HIP_EINVAL, "normal modifier is a colour image");
+        if (s.albedo_tex || s.normal_tex) ext = true;
+    }
+    if (d->n_textures && (!d->textures || !d->tex_data)) return fail(NORI_HIP_EINVAL, "textures is null");
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const NoriHipTexture &t = d->textures[i];
+        if (t.kind > NORI_HIP_TEX_NORMAL || t.lookup > NORI_HIP_LOOKUP_BILINEAR) return fail(NORI_HIP_EINVAL, "unknown texture kind or lookup");
+        if (t.width == 0 || t.height == 0 || (t.offset & 3u) || t.offset + (uint64_t) t.width * t.height * 4u > d->n_tex_bytes)
+            return fail(NORI_HIP_EINVAL, "texture " + std::to_string(i) + " lies outside tex_data");
+        if (t.scale[0] == 0.f || t.scale[1] == 0.f) return fail(NORI_HIP_EINVAL, "texture scale is zero");
     }
     for (uint32_t i = 0; i < d->n_emitters; ++i) {
         const NoriHipEmitter &e = d->emitters[i];
@@ -927,9 +960,13 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     if ((rc = upload(ctx->d_shapes, d->shapes, d->n_shapes))) return rc;
     if ((rc = upload(ctx->d_emitters, d->emitters, d->n_emitters))) return rc;
     if ((rc = upload(ctx->d_cdf, d->cdf, d->n_cdf))) return rc;
+    if ((rc = upload(ctx->d_textures, d->textures, d->n_textures))) return rc;
+    if ((rc = upload(ctx->d_tex_data, d->tex_data, d->n_textures ? (size_t) d->n_tex_bytes : 0))) return rc;
+    ctx->ext = ext;
     DevScene &sc = ctx->sc;
     sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
+    sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
     sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = ctx->ordered ? 1 : 0;
     for (int i = 0; i < 3; ++i) { sc.root_min[i] = d->root_min[i]; sc.root_max[i] = d->root_max[i]; }
     sc.cam = d->camera;
@@ -1002,8 +1039,12 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     HIPCHK(hipMalloc((void **) &d_sq, n * 8)); HIPCHK(hipMemcpyAsync(d_sq, seqs, n * 8, hipMemcpyHostToDevice, ctx->stream));
     if (rays) { HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay))); HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream)); }
     HIPCHK(hipMalloc((void **) &d_rgb, n * 12));
-    hipLaunchKernelGGL(k_li_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
-                       (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
+    if (ctx->ext)
+        hipLaunchKernelGGL(k_li_samples<true>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
+                           (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
+    else
+        hipLaunchKernelGGL(k_li_samples<false>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
+                           (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1032,7 +1073,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         const unsigned int n_cached = share > stack_bytes ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((share - stack_bytes) / 64)) : 0u;
         const size_t lds = stack_bytes + (size_t) n_cached * 64;
         void (*kern)(DevScene, RenderJob, float4 *, unsigned long long *, DevStats *, unsigned int) =
-            W == 3 ? k_render_w3 : W == 4 ? k_render_w4 : W == 5 ? k_render_w5 : W == 6 ? k_render_w6 : k_render_w8;
+            ctx->ext ? k_render_ext : W == 3 ? k_render_w3 : W == 4 ? k_render_w4 : W == 5 ? k_render_w5 : W == 6 ? k_render_w6 : k_render_w8;
         HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(MEGA_THREADS), lds, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats, n_cached);
@@ -1082,7 +1123,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
     const int SW = ctx->shade_waves;
     void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, unsigned int *, WfCounters *, unsigned long long *, DevStats *) =
-        SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
+        ctx->ext ? k_shade_ext : SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     uint64_t it = 0;
     for (;; ++it) {
@@ -1118,8 +1159,9 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
             if (n_upper == 0) break;
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
-                hipLaunchKernelGGL(k_finish, dim3(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u))), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film,
-                                   (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u)));
+                if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
                 ++it;
                 break;

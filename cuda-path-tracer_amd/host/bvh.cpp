@@ -182,6 +182,16 @@ void flattenScene(const Scene *scene, FlatScene &out) {
     // shapes, emitters, area CDFs
     const auto &lights = scene->getLights();
     out.shapes.resize(shapes.size());
+    // images: one table entry per distinct plugin object; returns the 1-based index the shape records hold
+    std::vector<const ImageData *> seen;
+    auto addImage = [&](const ImageData *img) -> uint32_t {
+        if (!img) return 0u;
+        for (size_t k = 0; k < seen.size(); ++k) if (seen[k] == img) return (uint32_t) k + 1;
+        NoriHipTexture t = img->meta; t.offset = out.tex_data.size();
+        out.tex_data.insert(out.tex_data.end(), img->texels.begin(), img->texels.end());
+        out.textures.push_back(t); seen.push_back(img);
+        return (uint32_t) out.textures.size();
+    };
     for (size_t s = 0; s < shapes.size(); ++s) {
         NoriHipShape &d = out.shapes[s]; std::memset(&d, 0, sizeof(d));
         const Shape *sh = shapes[s];
@@ -189,6 +199,8 @@ void flattenScene(const Scene *scene, FlatScene &out) {
         d.alpha = 0.1f; d.int_ior = 1.5046f; d.ext_ior = 1.000277f; d.ks = 0.5f;
         sh->getBSDF()->describe(d);
         d.emitter = -1;
+        d.albedo_tex = addImage(sh->getBSDF()->albedoImage());
+        d.normal_tex = addImage(sh->getNormalModifier() ? sh->getNormalModifier()->image() : nullptr);
         if (sh->isSphere()) { const Sphere *sp = static_cast<const Sphere *>(sh); Point3f c = sp->getCenter(); d.center[0] = c.x; d.center[1] = c.y; d.center[2] = c.z; d.radius = sp->getRadius(); }
         else { const Mesh *m = static_cast<const Mesh *>(sh); d.flags = (m->getVertexNormals().empty() ? 0u : 1u) | (m->getVertexTexCoords().empty() ? 0u : 2u); }
     }
@@ -267,6 +279,8 @@ void flattenScene(const Scene *scene, FlatScene &out) {
     d.n_emitters = (uint32_t) out.emitters.size(); d.emitters = out.emitters.empty() ? nullptr : out.emitters.data();
     d.n_cdf = (uint32_t) out.cdf.size(); d.cdf = out.cdf.empty() ? nullptr : out.cdf.data();
     d.n_light_prims = (uint32_t) out.light_prims.size(); d.light_prims = out.light_prims.empty() ? nullptr : out.light_prims.data();
+    d.n_textures = (uint32_t) out.textures.size(); d.textures = out.textures.empty() ? nullptr : out.textures.data();
+    d.n_tex_bytes = out.tex_data.size(); d.tex_data = out.tex_data.empty() ? nullptr : out.tex_data.data();
     scene->getCamera()->describe(d.camera);
 }
 

@@ -239,8 +239,13 @@ NoriObject *loadFromXML(const std::string &filename) {
                     case EFloat: checkAttributes(node, {"name", "value"}); list.setFloat(node.attr("name"), toFloat(node.attr("value"))); break;
                     case EInteger: checkAttributes(node, {"name", "value"}); list.setInteger(node.attr("name"), toInt(node.attr("value"))); break;
                     case EBoolean: checkAttributes(node, {"name", "value"}); list.setBoolean(node.attr("name"), toBool(node.attr("value"))); break;
-                    case EPoint: checkAttributes(node, {"name", "value"}); list.setPoint3(node.attr("name"), toVector3f(node.attr("value"))); break;
-                    case EVector: checkAttributes(node, {"name", "value"}); list.setVector3(node.attr("name"), toVector3f(node.attr("value"))); break;
+                    case EPoint: case EVector: {                           // 2 or 3 components (src/parser.cpp:242-266)
+                        checkAttributes(node, {"name", "value"});
+                        std::vector<std::string> tk = tokenize(node.attr("value"));
+                        if (tk.size() == 2) { Point2f v(toFloat(tk[0]), toFloat(tk[1])); if (tag == EPoint) list.setPoint2(node.attr("name"), v); else list.setVector2(node.attr("name"), v); }
+                        else if (tk.size() == 3) { if (tag == EPoint) list.setPoint3(node.attr("name"), toVector3f(node.attr("value"))); else list.setVector3(node.attr("name"), toVector3f(node.attr("value"))); }
+                        else throw NoriException::format("%s %s (value: %s) is not of size 2 or 3", tag == EPoint ? "Point" : "Vector", node.attr("name").c_str(), node.attr("value").c_str());
+                    } break;
                     case EColor: checkAttributes(node, {"name", "value"}); list.setColor(node.attr("name"), toVector3f(node.attr("value"))); break;
                     case ETransform: checkAttributes(node, {"name"}); list.setTransform(node.attr("name"), transform.toTransform()); break;
                     case ETranslate: { checkAttributes(node, {"value"}); Vector3f v = toVector3f(node.attr("value")); for (int i = 0; i < 3; ++i) transform.t[i] += v[i]; } break;

@@ -89,7 +89,9 @@ public:
     void setPoint3(const std::string &n, const Point3f &v) { p[n] = v; }
     void setVector3(const std::string &n, const Vector3f &v) { p[n] = v; }
     void setTransform(const std::string &n, const Transform &v) { t[n] = v; }
-    bool has(const std::string &n) const { return b.count(n) || i.count(n) || f.count(n) || s.count(n) || c.count(n) || p.count(n) || t.count(n); }
+    void setPoint2(const std::string &n, const Point2f &v) { p2[n] = v; }       // 2-component <point>/<vector> (src/parser.cpp:242-266)
+    void setVector2(const std::string &n, const Point2f &v) { p2[n] = v; }
+    bool has(const std::string &n) const { return b.count(n) || i.count(n) || f.count(n) || s.count(n) || c.count(n) || p.count(n) || t.count(n) || p2.count(n); }
 #define NORI_GETTER(Type, Name, member) \
     Type get##Name(const std::string &n) const { auto it = member.find(n); if (it == member.end()) { if (has(n)) throw NoriException::format("Property '%s' has the wrong type!", n.c_str()); throw NoriException::format("Property '%s' is missing!", n.c_str()); } return it->second; } \
     Type get##Name(const std::string &n, const Type &d) const { auto it = member.find(n); if (it == member.end()) { if (has(n)) throw NoriException::format("Property '%s' has the wrong type!", n.c_str()); return d; } return it->second; }
@@ -101,10 +103,12 @@ public:
     NORI_GETTER(Point3f, Point3, p)
     NORI_GETTER(Vector3f, Vector3, p)
     NORI_GETTER(Transform, Transform, t)
+    NORI_GETTER(Point2f, Point2, p2)
+    NORI_GETTER(Point2f, Vector2, p2)
 #undef NORI_GETTER
 private:
     std::map<std::string, bool> b; std::map<std::string, int> i; std::map<std::string, float> f; std::map<std::string, std::string> s;
-    std::map<std::string, Color3f> c; std::map<std::string, Point3f> p; std::map<std::string, Transform> t;
+    std::map<std::string, Color3f> c; std::map<std::string, Point3f> p; std::map<std::string, Transform> t; std::map<std::string, Point2f> p2;
 };
 
 /// Base class of everything that can be named in a scene file (include/nori/object.h:31-123)

@@ -13,7 +13,7 @@
 namespace nori {
 
 // ---- Shape ------------------------------------------------------------------------------------------------
-Shape::~Shape() { delete m_bsdf; }
+Shape::~Shape() { delete m_bsdf; delete m_normalModifier; }
 void Shape::activate() {
     if (!m_bsdf) { m_bsdf = static_cast<BSDF *>(NoriObjectFactory::createInstance("diffuse", PropertyList())); m_bsdf->activate(); }
 }
@@ -25,6 +25,9 @@ void Shape::addChild(NoriObject *obj) {
         case EEmitter:
             if (m_emitter) throw NoriException("Shape: tried to register multiple Emitter instances!");
             m_emitter = static_cast<Emitter *>(obj); m_emitter->setShape(this); break;
+        case ENormalModifier:                                // cuda/nori/shape.cpp:58-63
+            if (m_normalModifier) throw NoriException("Shape: tried to register multiple Normal modifier instances!");
+            m_normalModifier = static_cast<NormalModifier *>(obj); break;
         default:
             throw NoriException::format("Shape::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
     }
@@ -136,37 +139,180 @@ NORI_REGISTER_CLASS(Sphere, "sphere")
 // ---- BSDFs ------------------------------------------------------------------------------------------------
 static std::string colorStr(const Color3f &c) { char b[96]; snprintf(b, sizeof(b), "[%f, %f, %f]", c.x, c.y, c.z); return b; }
 
-/// constant_color texture: the only texture the CPU reference can evaluate without OpenCV (src/consttexture.cpp)
-class ConstantColorTexture : public NoriObject {
+// ---- images ------------------------------------------------------------------------------------------------
+static bool readPnm(const std::string &path, int &cols, int &rows, int &channels, std::vector<uint8_t> &data) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    char magic[2] = {0, 0}; f.read(magic, 2);
+    if (magic[0] != 'P' || (magic[1] != '5' && magic[1] != '6')) return false;
+    auto nextInt = [&]() -> int {                             // header integers, '#' comments skipped
+        int c = f.get();
+        for (;;) { while (c == ' ' || c == '\t' || c == '\r' || c == '\n') c = f.get(); if (c == '#') { while (c != '\n' && c != EOF) c = f.get(); } else break; }
+        int v = 0; bool any = false;
+        while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); any = true; c = f.get(); }
+        if (!any) throw NoriException::format("Image %s: malformed PNM header", path.c_str());
+        return v;                                             // the single whitespace after the last header field is consumed
+    };
+    cols = nextInt(); rows = nextInt(); int maxv = nextInt();
+    if (cols <= 0 || rows <= 0 || maxv != 255) throw NoriException::format("Image %s: only 8-bit PNM images are supported", path.c_str());
+    channels = magic[1] == '6' ? 3 : 1;
+    data.resize((size_t) cols * rows * channels);
+    f.read(reinterpret_cast<char *>(data.data()), (std::streamsize) data.size());
+    if ((size_t) f.gcount() != data.size()) throw NoriException::format("Image %s: truncated pixel data", path.c_str());
+    return true;
+}
+void loadImageFile(const std::string &filename, int &cols, int &rows, int &channels, std::vector<uint8_t> &data) {
+    for (const std::string &cand : {filename, filename + ".ppm", filename + ".pgm"})
+        if (readPnm(getFileResolver()->resolve(cand), cols, rows, channels, data)) return;
+    throw NoriException::format("Image %s could not be found! (this build decodes binary PNM only: place a pre-decoded %s.ppm or .pgm next to it)", filename.c_str(), filename.c_str());
+}
+static void imageCommon(const PropertyList &p, ImageData &img, uint32_t kind) {
+    std::memset(&img.meta, 0, sizeof(img.meta));
+    Point2f delta = p.getPoint2("delta", Point2f(0.f, 0.f)), scale = p.getVector2("scale", Point2f(1.f, 1.f));
+    img.meta.kind = kind; img.meta.delta[0] = delta.x; img.meta.delta[1] = delta.y; img.meta.scale[0] = scale.x; img.meta.scale[1] = scale.y;
+    // "lookup": "bilinear" = the CUDA fork's tex2D, "nearest" = the CPU renderer's truncating lookup (colour images)
+    std::string lk = p.getString("lookup", "bilinear");
+    if (lk == "bilinear") img.meta.lookup = NORI_HIP_LOOKUP_BILINEAR; else if (lk == "nearest") img.meta.lookup = NORI_HIP_LOOKUP_NEAREST;
+    else throw NoriException::format("Unknown texture lookup \"%s\"", lk.c_str());
+}
+static void rgbaTexels(const std::string &filename, ImageData &img) {
+    int cols, rows, ch; std::vector<uint8_t> px; loadImageFile(filename, cols, rows, ch, px);
+    img.meta.width = (uint32_t) cols; img.meta.height = (uint32_t) rows; img.texels.resize((size_t) cols * rows * 4);
+    for (size_t i = 0; i < (size_t) cols * rows; ++i) {       // cv::cvtColor(BGR2RGBA): alpha = 255
+        uint8_t r = ch == 3 ? px[3 * i] : px[i], g = ch == 3 ? px[3 * i + 1] : px[i], b = ch == 3 ? px[3 * i + 2] : px[i];
+        img.texels[4 * i] = r; img.texels[4 * i + 1] = g; img.texels[4 * i + 2] = b; img.texels[4 * i + 3] = 255;
+    }
+}
+
+/// constant_color texture (src/consttexture.cpp)
+class ConstantColorTexture : public ColorTexture {
 public:
     explicit ConstantColorTexture(const PropertyList &p) { m_value = p.getColor("value", Color3f(0.f)); }
-    EClassType getClassType() const override { return ETexture; }
-    Color3f eval(const Point2f &) const { return m_value; }
+    Color3f constantValue() const override { return m_value; }
     std::string toString() const override { return "ConstantTexture[ " + colorStr(m_value) + " ]"; }
 private:
     Color3f m_value;
 };
 NORI_REGISTER_CLASS(ConstantColorTexture, "constant_color")
 
-class Diffuse : public BSDF {
+/// image_color texture (cuda/nori/imagetexture.cpp.cu:29-52; src/imagetexture.cpp:100-111)
+class ImageColorTexture : public ColorTexture {
 public:
-    explicit Diffuse(const PropertyList &propList) { if (propList.has("albedo")) { m_albedo = propList.getColor("albedo"); m_has = true; } }
-    void addChild(NoriObject *obj) override {
-        if (obj->getClassType() != ETexture) throw NoriException::format("Diffuse::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
+    explicit ImageColorTexture(const PropertyList &p) {
+        imageCommon(p, m_img, NORI_HIP_TEX_COLOR);
+        rgbaTexels(p.getString("filename"), m_img);
+    }
+    const ImageData *image() const override { return &m_img; }
+    std::string toString() const override { return "ImageTexture[]"; }
+private:
+    ImageData m_img;
+};
+NORI_REGISTER_CLASS(ImageColorTexture, "image_color")
+
+/// bump_map (cuda/nori/bumpMap.cpp.cu:31-115): grey image -> Sobel gradients in x and y, 16-bit signed
+class BumpMap : public NormalModifier {
+public:
+    explicit BumpMap(const PropertyList &p) {
+        imageCommon(p, m_img, NORI_HIP_TEX_BUMP);
+        const float height = p.getFloat("height", 5), gradDelta = p.getFloat("grad_delta", 0);
+        int cols, rows, ch; std::vector<uint8_t> px; loadImageFile(p.getString("filename"), cols, rows, ch, px);
+        std::vector<uint8_t> grey((size_t) cols * rows);
+        for (size_t i = 0; i < grey.size(); ++i)             // cv::imread(..., GRAYSCALE) of a colour file: fixed-point BT.601 luma
+            grey[i] = ch == 1 ? px[i] : (uint8_t) ((px[3 * i] * 4899 + px[3 * i + 1] * 9617 + px[3 * i + 2] * 1868 + 8192) >> 14);
+        m_img.meta.width = (uint32_t) cols; m_img.meta.height = (uint32_t) rows; m_img.texels.resize(grey.size() * 4);
+        // cv::Sobel(image, grad, CV_16S, dx, dy, 3, height, grad_delta, BORDER_DEFAULT): 3x3 kernels, reflect-101 border,
+        // result = saturate_cast<short>(sum * scale + delta)
+        auto at = [&](int r, int c) -> int {
+            if (rows > 1) { if (r < 0) r = -r; if (r >= rows) r = 2 * rows - 2 - r; } else r = 0;
+            if (cols > 1) { if (c < 0) c = -c; if (c >= cols) c = 2 * cols - 2 - c; } else c = 0;
+            return grey[(size_t) r * cols + c];
+        };
+        auto sat = [](float v) -> int16_t { long q = lrintf(v); return (int16_t) (q < -32768 ? -32768 : q > 32767 ? 32767 : q); };
+        for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) {
+            int gx = (at(r - 1, c + 1) + 2 * at(r, c + 1) + at(r + 1, c + 1)) - (at(r - 1, c - 1) + 2 * at(r, c - 1) + at(r + 1, c - 1));
+            int gy = (at(r + 1, c - 1) + 2 * at(r + 1, c) + at(r + 1, c + 1)) - (at(r - 1, c - 1) + 2 * at(r - 1, c) + at(r - 1, c + 1));
+            int16_t sx = sat((float) gx * height + gradDelta), sy = sat((float) gy * height + gradDelta);
+            std::memcpy(&m_img.texels[((size_t) r * cols + c) * 4], &sx, 2); std::memcpy(&m_img.texels[((size_t) r * cols + c) * 4 + 2], &sy, 2);
+        }
+    }
+    const ImageData *image() const override { return &m_img; }
+    std::string toString() const override { return "BumpMap[]"; }
+private:
+    ImageData m_img;
+};
+NORI_REGISTER_CLASS(BumpMap, "bump_map")
+
+/// normal_map (cuda/nori/normalMap.cpp.cu:28-97)
+class NormalMap : public NormalModifier {
+public:
+    explicit NormalMap(const PropertyList &p) {
+        imageCommon(p, m_img, NORI_HIP_TEX_NORMAL);
+        rgbaTexels(p.getString("filename"), m_img);
+    }
+    const ImageData *image() const override { return &m_img; }
+    std::string toString() const override { return "NormalMap[]"; }
+private:
+    ImageData m_img;
+};
+NORI_REGISTER_CLASS(NormalMap, "normal_map")
+
+/// What Diffuse and Subsurface share: the "albedo" slot, a colour property or a texture child
+/// (src/diffuse.cpp:31-72, src/subsurface.cpp:32-88)
+class AlbedoSlot {
+public:
+    ~AlbedoSlot() { delete m_tex; }
+    void fromProps(const PropertyList &p) { if (p.has("albedo")) { m_value = p.getColor("albedo"); m_has = true; } }
+    void addChild(NoriObject *obj, const char *cls) {
+        if (obj->getClassType() != NoriObject::ETexture) throw NoriException::format("%s::addChild(<%s>) is not supported!", cls, NoriObject::classTypeName(obj->getClassType()).c_str());
         if (obj->getIdName() != "albedo") throw NoriException("The name of this texture does not match any field!");
         if (m_has) throw NoriException("There is already an albedo defined!");
-        ConstantColorTexture *t = dynamic_cast<ConstantColorTexture *>(obj);
-        if (!t) throw NoriException("Diffuse: only constant_color albedo textures are supported by this build");
-        m_albedo = t->eval(Point2f()); m_has = true; delete obj;
+        m_tex = static_cast<ColorTexture *>(obj); m_has = true;
+        if (!m_tex->image()) m_value = m_tex->constantValue();
     }
-    void activate() override { if (!m_has) { m_albedo = Color3f(0.5f); m_has = true; } }
-    bool isDelta() const override { return false; }
-    void describe(NoriHipShape &o) const override { o.bsdf = NORI_HIP_BSDF_DIFFUSE; o.albedo[0] = m_albedo.x; o.albedo[1] = m_albedo.y; o.albedo[2] = m_albedo.z; }
-    std::string toString() const override { return "Diffuse[\n  albedo = ConstantTexture[ " + colorStr(m_albedo) + " ]\n]"; }
+    void activate() { if (!m_has) { m_value = Color3f(0.5f); m_has = true; } }
+    void describe(NoriHipShape &o) const { o.albedo[0] = m_value.x; o.albedo[1] = m_value.y; o.albedo[2] = m_value.z; }
+    const ImageData *image() const { return m_tex ? m_tex->image() : nullptr; }
+    std::string toString() const { return image() ? std::string("ImageTexture[]") : "ConstantTexture[ " + colorStr(m_value) + " ]"; }
 private:
-    Color3f m_albedo; bool m_has = false;
+    Color3f m_value; bool m_has = false; ColorTexture *m_tex = nullptr;
+};
+
+class Diffuse : public BSDF {
+public:
+    explicit Diffuse(const PropertyList &propList) { m_albedo.fromProps(propList); }
+    void addChild(NoriObject *obj) override { m_albedo.addChild(obj, "Diffuse"); }
+    void activate() override { m_albedo.activate(); }
+    bool isDelta() const override { return false; }
+    void describe(NoriHipShape &o) const override { o.bsdf = NORI_HIP_BSDF_DIFFUSE; m_albedo.describe(o); }
+    const ImageData *albedoImage() const override { return m_albedo.image(); }
+    std::string toString() const override { return "Diffuse[\n  albedo = " + m_albedo.toString() + "\n]"; }
+private:
+    AlbedoSlot m_albedo;
 };
 NORI_REGISTER_CLASS(Diffuse, "diffuse")
+
+/// subsurface (src/subsurface.cpp:29-88): diffuse transmission whose exit point is found with a probe ray
+class Subsurface : public BSDF {
+public:
+    explicit Subsurface(const PropertyList &p) {
+        m_albedo.fromProps(p);
+        m_intIOR = p.getFloat("intIOR", 1.3046f); m_extIOR = p.getFloat("extIOR", 1.000277f);
+        m_sigmaT = p.getColor("sigma_t", Color3f(0.01f)); m_dmfp = p.getColor("dmfp", Color3f(0.1f));
+    }
+    void addChild(NoriObject *obj) override { m_albedo.addChild(obj, "Subsurface"); }
+    void activate() override { m_albedo.activate(); }
+    bool isDelta() const override { return false; }
+    void describe(NoriHipShape &o) const override {
+        o.bsdf = NORI_HIP_BSDF_SUBSURFACE; m_albedo.describe(o); o.int_ior = m_intIOR; o.ext_ior = m_extIOR;
+        auto colorNorm = [](const Color3f &c) { return std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z); };     // src/subsurface.cpp:94-97
+        o.ss_cs = colorNorm(Color3f(1.0f)); o.ss_cd = colorNorm(m_dmfp);                                     // s = 1 (:91)
+    }
+    const ImageData *albedoImage() const override { return m_albedo.image(); }
+    std::string toString() const override { return "Subsurface[\n  albedo = " + m_albedo.toString() + "\n]"; }
+private:
+    AlbedoSlot m_albedo; float m_intIOR, m_extIOR; Color3f m_sigmaT, m_dmfp;
+};
+NORI_REGISTER_CLASS(Subsurface, "subsurface")
 
 class Microfacet : public BSDF {
 public:

@@ -9,11 +9,35 @@
 
 namespace nori {
 
+/// An image as the device reads it (include/nori_hip.h: NoriHipTexture + 4 bytes per texel); `meta.offset` is set
+/// when the scene is flattened.
+struct ImageData { NoriHipTexture meta; std::vector<uint8_t> texels; };
+/// Decodes a binary PNM (P5 grey / P6 colour, 8 bit), `filename` being looked up through the file resolver as the
+/// reference does (cuda/nori/imagetexture.cpp.cu:36).  For any other format the pre-decoded sibling "<file>.ppm" /
+/// "<file>.pgm" is read instead (the reference decodes with cv::imread, which this build does not have).
+/// Returns rows x cols x channels bytes, channels = 1 or 3 (RGB order).
+void loadImageFile(const std::string &filename, int &cols, int &rows, int &channels, std::vector<uint8_t> &data);
+
+/// Texture<Color3f> (include/nori/texture.h): a constant colour or an image
+class ColorTexture : public NoriObject {
+public:
+    EClassType getClassType() const override { return ETexture; }
+    virtual Color3f constantValue() const { return Color3f(0.f); }
+    virtual const ImageData *image() const { return nullptr; }
+};
+/// NormalModifier (include/nori/normalModifier.h; cuda/include/nori/bumpMap.h, normalMap.h)
+class NormalModifier : public NoriObject {
+public:
+    EClassType getClassType() const override { return ENormalModifier; }
+    virtual const ImageData *image() const = 0;
+};
+
 class BSDF : public NoriObject {
 public:
     EClassType getClassType() const override { return EBSDF; }
     virtual bool isDelta() const = 0;
     virtual void describe(NoriHipShape &out) const = 0;      // fills bsdf kind + parameters
+    virtual const ImageData *albedoImage() const { return nullptr; }
 };
 
 class Shape;
@@ -38,12 +62,13 @@ public:
     Emitter *getEmitter() { return m_emitter; }
     const Emitter *getEmitter() const { return m_emitter; }
     const BSDF *getBSDF() const { return m_bsdf; }
+    const NormalModifier *getNormalModifier() const { return m_normalModifier; }
     virtual uint32_t getPrimitiveCount() const { return 1; }
     virtual BoundingBox3f getBoundingBox(uint32_t index) const = 0;
     virtual Point3f getCentroid(uint32_t index) const = 0;
     virtual bool isSphere() const { return false; }
 protected:
-    BSDF *m_bsdf = nullptr; Emitter *m_emitter = nullptr; BoundingBox3f m_bbox;
+    BSDF *m_bsdf = nullptr; Emitter *m_emitter = nullptr; NormalModifier *m_normalModifier = nullptr; BoundingBox3f m_bbox;
 };
 
 /// Indexed triangle mesh, struct-of-arrays (include/nori/mesh.h)
@@ -173,6 +198,7 @@ private:
 struct FlatScene {
     std::vector<NoriHipNode> nodes; std::vector<NoriHipPrim> prims; std::vector<NoriHipShadePrim> shade, light_prims;
     std::vector<NoriHipShape> shapes; std::vector<NoriHipEmitter> emitters; std::vector<float> cdf;
+    std::vector<NoriHipTexture> textures; std::vector<uint8_t> tex_data;
     NoriHipSceneDesc desc;
 };
 /// Scene graph -> C ABI tables (replaces the object-by-object marshalling of cuda/CudaRender.cpp:80-98)

@@ -25,7 +25,8 @@ class SceneDesc(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("nodes", C.c_void_p), ("n_prims", C.c_uint32), ("prims", C.c_void_p), ("shade_prims", C.c_void_p),
                 ("root", C.c_uint32), ("root_min", C.c_float * 3), ("root_max", C.c_float * 3),
                 ("n_shapes", C.c_uint32), ("shapes", C.c_void_p), ("n_emitters", C.c_uint32), ("emitters", C.c_void_p),
-                ("n_cdf", C.c_uint32), ("cdf", C.c_void_p), ("n_light_prims", C.c_uint32), ("light_prims", C.c_void_p), ("camera", Camera)]
+                ("n_cdf", C.c_uint32), ("cdf", C.c_void_p), ("n_light_prims", C.c_uint32), ("light_prims", C.c_void_p), ("camera", Camera),
+                ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_tex_bytes", C.c_uint64), ("tex_data", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -41,13 +42,15 @@ PRIM_DTYPE = np.dtype([("a", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("pr
 SHADE_DTYPE = np.dtype([("p0", "<f4", 3), ("p1", "<f4", 3), ("p2", "<f4", 3), ("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
                         ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("uv2", "<f4", 2)])
 SHAPE_DTYPE = np.dtype([("type", "<i4"), ("bsdf", "<i4"), ("emitter", "<i4"), ("flags", "<u4"), ("albedo", "<f4", 3), ("alpha", "<f4"),
-                        ("int_ior", "<f4"), ("ext_ior", "<f4"), ("ks", "<f4"), ("center", "<f4", 3), ("radius", "<f4"), ("pad", "<u4")])
+                        ("int_ior", "<f4"), ("ext_ior", "<f4"), ("ks", "<f4"), ("center", "<f4", 3), ("radius", "<f4"), ("albedo_tex", "<u4"),
+                        ("normal_tex", "<u4"), ("ss_cs", "<f4"), ("ss_cd", "<f4"), ("pad", "<u4")])
+TEXTURE_DTYPE = np.dtype([("kind", "<u4"), ("lookup", "<u4"), ("width", "<u4"), ("height", "<u4"), ("offset", "<u8"), ("scale", "<f4", 2), ("delta", "<f4", 2)])
 EMITTER_DTYPE = np.dtype([("radiance", "<f4", 3), ("shape", "<i4"), ("cdf_offset", "<u4"), ("n_tris", "<u4"), ("light_prim_offset", "<u4"),
                           ("area_pdf", "<f4")])
 NODE32_DTYPE = np.dtype([("w0", "<u4"), ("w1", "<u4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3)])
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("mint", "<f4"), ("d", "<f4", 3), ("maxt", "<f4")])
 HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
-assert NODE_DTYPE.itemsize == 64 and PRIM_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 96 and SHAPE_DTYPE.itemsize == 64 and EMITTER_DTYPE.itemsize == 32
+assert NODE_DTYPE.itemsize == 64 and PRIM_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 96 and SHAPE_DTYPE.itemsize == 80 and EMITTER_DTYPE.itemsize == 32 and TEXTURE_DTYPE.itemsize == 40
 
 MISS = 0xFFFFFFFF
 _hip = None
@@ -309,7 +312,8 @@ class HostScene:
         return dict(desc=d, nodes=_from_ptr(d.nodes, d.n_nodes, NODE_DTYPE), prims=_from_ptr(d.prims, d.n_prims, PRIM_DTYPE),
                     shade=_from_ptr(d.shade_prims, d.n_prims, SHADE_DTYPE), shapes=_from_ptr(d.shapes, d.n_shapes, SHAPE_DTYPE),
                     emitters=_from_ptr(d.emitters, d.n_emitters, EMITTER_DTYPE), cdf=_from_ptr(d.cdf, d.n_cdf, np.float32),
-                    light_prims=_from_ptr(d.light_prims, d.n_light_prims, SHADE_DTYPE))
+                    light_prims=_from_ptr(d.light_prims, d.n_light_prims, SHADE_DTYPE),
+                    textures=_from_ptr(d.textures, d.n_textures, TEXTURE_DTYPE), tex_data=_from_ptr(d.tex_data, d.n_tex_bytes, np.uint8))
 
     def preprocess(self, scene=0, device=-1):
         _ochk(self.L.nori_host_preprocess(self.h, scene, device))

@@ -29,9 +29,14 @@ extern "C" {
 #define NORI_HIP_NO_CHILD   0xffffffffu   /* child reference: absent (only in the dummy root of a 1-leaf tree) */
 #define NORI_HIP_MISS       0xffffffffu   /* NoriHipHit.prim for a ray that hit nothing */
 
-/* BSDF / shape kinds (src/diffuse.cpp, src/microfacet.cpp, src/dielectric.cpp, src/mirror.cpp; src/mesh.cpp, src/sphere.cpp) */
-enum { NORI_HIP_BSDF_DIFFUSE = 0, NORI_HIP_BSDF_MICROFACET = 1, NORI_HIP_BSDF_DIELECTRIC = 2, NORI_HIP_BSDF_MIRROR = 3 };
+/* BSDF / shape kinds (src/diffuse.cpp, src/microfacet.cpp, src/dielectric.cpp, src/mirror.cpp, src/subsurface.cpp;
+ * src/mesh.cpp, src/sphere.cpp) */
+enum { NORI_HIP_BSDF_DIFFUSE = 0, NORI_HIP_BSDF_MICROFACET = 1, NORI_HIP_BSDF_DIELECTRIC = 2, NORI_HIP_BSDF_MIRROR = 3,
+       NORI_HIP_BSDF_SUBSURFACE = 4 };
 enum { NORI_HIP_SHAPE_MESH = 0, NORI_HIP_SHAPE_SPHERE = 1 };
+/* image kinds and lookup modes (cuda/nori/imagetexture.cpp.cu, bumpMap.cpp.cu, normalMap.cpp.cu; src/imagetexture.cpp) */
+enum { NORI_HIP_TEX_COLOR = 0, NORI_HIP_TEX_BUMP = 1, NORI_HIP_TEX_NORMAL = 2 };
+enum { NORI_HIP_LOOKUP_NEAREST = 0, NORI_HIP_LOOKUP_BILINEAR = 1 };
 
 /*
  * 64-byte BVH node: one inner node of the reference tree with BOTH children's boxes, so one aligned 64-B fetch
@@ -78,8 +83,29 @@ typedef struct NoriHipShape {
     float    albedo[3];            /* diffuse albedo | microfacet kd */
     float    alpha, int_ior, ext_ior, ks;
     float    center[3], radius;    /* sphere */
+    uint32_t albedo_tex;           /* 0: `albedo` is the constant colour; k: textures[k-1] (NORI_HIP_TEX_COLOR) gives it */
+    uint32_t normal_tex;           /* 0: none; k: textures[k-1] (NORI_HIP_TEX_BUMP / _NORMAL) replaces the shading normal */
+    float    ss_cs, ss_cd;         /* subsurface: colorNorm(s), colorNorm(dmfp) (src/subsurface.cpp:94-97,108-119) */
     uint32_t pad;
 } NoriHipShape;
+
+/*
+ * One image, 4 bytes per texel, rows x cols, row-major at tex_data + offset.  Replaces the cv::Mat members and
+ * cudaTextureObject_t of ImageTexture<Color3f>, BumpMap and NormalMap (cuda/nori/imagetexture.cpp.cu:67-104,
+ * bumpMap.cpp.cu:55-115, normalMap.cpp.cu:52-97).
+ *   NORI_HIP_TEX_COLOR / _NORMAL : texel = R, G, B, A bytes (the fork converts BGR -> RGBA before upload)
+ *   NORI_HIP_TEX_BUMP            : texel = two int16: Sobel d/dx, d/dy of the grey image (cv::Sobel, CV_16S, ksize 3,
+ *                                  scale = height, delta = grad_delta), read as value / 32767
+ * lookup: NORI_HIP_LOOKUP_BILINEAR is the CUDA fork's tex2D (wrap addressing, normalised coordinates, 8-bit blend
+ * weights) and, for colour images, its sRGB -> linear conversion; NORI_HIP_LOOKUP_NEAREST is the CPU renderer's
+ * lookup for colour images (src/imagetexture.cpp:49-77: row = x*rows, col = y*cols, no colour-space conversion).
+ */
+typedef struct NoriHipTexture {
+    uint32_t kind, lookup;
+    uint32_t width, height;        /* image.cols, image.rows */
+    uint64_t offset;               /* byte offset of texel (row 0, col 0) in tex_data; multiple of 4 */
+    float    scale[2], delta[2];   /* uv -> (uv / scale) - delta, then the fractional part (imagetexture.cpp.cu:15-20) */
+} NoriHipTexture;
 
 /* Area emitter bound to a shape (src/arealight.cpp).  Mesh emitters sample a triangle through the normalised
  * area CDF (include/nori/dpdf.h) stored at cdf[cdf_offset .. cdf_offset + n_tris], and read its vertices from
@@ -110,6 +136,8 @@ typedef struct NoriHipSceneDesc {
     uint32_t                n_cdf;     const float            *cdf;
     uint32_t                n_light_prims; const NoriHipShadePrim *light_prims;
     NoriHipCamera           camera;
+    uint32_t                n_textures; const NoriHipTexture  *textures;      /* may be 0 / NULL */
+    uint64_t                n_tex_bytes; const uint8_t        *tex_data;
 } NoriHipSceneDesc;
 
 /* ray in, 32 B: replaces Ray3f (include/nori/ray.h:38-100); dRcp is recomputed on the device */
@@ -120,7 +148,7 @@ typedef struct NoriHipHit { uint32_t prim; float t, u, v; } NoriHipHit;
 
 typedef struct NoriHipStats {
     uint64_t camera_samples;       /* samples started */
-    uint64_t closest_rays;         /* extend stage */
+    uint64_t closest_rays;         /* extend stage; includes the probe rays of subsurface hits (src/pathMisIntegrator.cpp:88-95) */
     uint64_t shadow_rays;          /* shadow stage */
     uint64_t invalid_samples;      /* dropped by the Color3f::isValid rule (src/block.cpp:94-98) */
     uint64_t boxes_tested;         /* slab tests performed (two per 64-byte node fetched, plus the root box) */

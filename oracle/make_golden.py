@@ -178,6 +178,8 @@ def bsdf_fixture():
         "dielectric_glass": (2, [0, 0, 0, 0.1, 1.5, 1.0]),
         "dielectric_water_glass": (2, [0, 0, 0, 0.1, 1.33, 1.5]),
         "mirror": (3, [0, 0, 0, 0.1, 1.5, 1.0]),
+        # src/subsurface.cpp: both sample arguments carry `sample` (the model draws wo from the second one)
+        "subsurface": (4, [0.9, 0.8, 0.7, 0.1, 1.3046, 1.000277]),
     }
     out = dict(wi=wi, sample=smp)
     print("== BSDF unit vectors")
@@ -189,6 +191,18 @@ def bsdf_fixture():
         out[k + "_type"] = t
         out[k + "_params"] = np.array(p, np.float32)
         out[k] = a
+    # Subsurface::sampleDx alone: probe ray and disk sample for hits at p with shading normal nrm, sampler seeded (i, 0)
+    p = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    out["ss_p"] = p
+    out["ss_n"] = nrm
+    for tag, dm in (("ss_dx_0p1", [0.1, 0.1, 0.1]), ("ss_dx_0p01", [0.01, 0.01, 0.01]), ("ss_dx_4", [4, 4, 4])):
+        a = R.ss_sample_dx(dm, p, nrm, np.arange(n), np.zeros(n))
+        b = O.ss_sample_dx(dm, p, nrm, np.arange(n), np.zeros(n))
+        print("   %-24s identical fraction %.5f" % (tag, (a == b).all(1).mean()))
+        out[tag + "_dmfp"] = np.array(dm, np.float32)
+        out[tag] = a
     np.savez_compressed(os.path.join(GOLD, "bsdf.npz"), **out)
 
 
@@ -230,7 +244,9 @@ def main():
               ("table", S + "/table/table_path_mis.xml", 64, 48, 2048, 3),
               ("table_microfacet", S + "/table/table_path_mis_microfacet.xml", 64, 48, 2048, 4),
               # 105 k triangles, depth-26 tree, a 960-triangle mesh emitter (CDF search) and an emitter of zero radiance
-              ("dragon", S + "/proj/dragon-diffuse.xml", 64, 48, 2048, 5)]
+              ("dragon", S + "/proj/dragon-diffuse.xml", 64, 48, 2048, 5),
+              # two subsurface shapes (sphere mesh dmfp 0.1, cube dmfp 0.01): probe rays with the shape mask, sampleDx retries
+              ("cbox_subsurface", S + "/proj/cbox_subsurface.xml", 64, 48, 4096, 6)]
     for sc in scenes:
         if not only or sc[0] in only:
             scene_fixture(*sc)

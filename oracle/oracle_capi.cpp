@@ -101,6 +101,36 @@ void orc_shape_copy(void *hp, int si, int shape, float *V, float *N, float *UV, 
     if (F) std::memcpy(F, s.F.data(), s.F.size() * sizeof(uint32_t));
     if (cdf && !s.cdf.empty()) std::memcpy(cdf, s.cdf.data(), s.cdf.size() * sizeof(float));
 }
+// images: info = kind, lookup (1 bilinear), cols, rows, then scale xy and delta xy as float bits; texels in the device layout
+// (4 bytes per texel: RGBA, or the two int16 gradients of a bump map)
+int orc_image_count(void *hp, int si) { const Scene *sc; const Accel *ac; sub(hp, si, &sc, &ac); return (int) sc->images.size(); }
+void orc_image_get(void *hp, int si, int k, int *info /*[4]*/, float *xform /*[4]*/, uint8_t *texels /* may be null */) {
+    const Scene *sc; const Accel *ac; sub(hp, si, &sc, &ac);
+    const Image &im = sc->images[k];
+    info[0] = im.kind; info[1] = im.bilinear ? 1 : 0; info[2] = im.cols; info[3] = im.rows;
+    xform[0] = im.scale.x; xform[1] = im.scale.y; xform[2] = im.delta.x; xform[3] = im.delta.y;
+    if (!texels) return;
+    const size_t N = (size_t) im.cols * im.rows;
+    if (im.kind == IMG_BUMP) for (size_t i = 0; i < N; ++i) { std::memcpy(texels + 4 * i, &im.gx[i], 2); std::memcpy(texels + 4 * i + 2, &im.gy[i], 2); }
+    else std::memcpy(texels, im.rgba.data(), N * 4);
+}
+// albedo image / normal modifier of a shape (-1: none) and its bsdf's subsurface dmfp
+void orc_shape_images(void *hp, int si, int shape, int *out /*[2]*/, float *dmfp /*[3]*/) {
+    const Scene *sc; const Accel *ac; sub(hp, si, &sc, &ac);
+    const Shape &s = sc->shapes[shape];
+    out[0] = s.bsdf.albedo_tex; out[1] = s.normal_tex; dmfp[0] = s.bsdf.dmfp.x; dmfp[1] = s.bsdf.dmfp.y; dmfp[2] = s.bsdf.dmfp.z;
+}
+// texture / modifier evaluation alone: colour of image k at uv, or the modified normal for shading normal nrm
+void orc_image_eval(void *hp, int si, int k, int n, const float *uv, const float *nrm, float *out /* n x 3 */) {
+    const Scene *sc; const Accel *ac; sub(hp, si, &sc, &ac);
+    const Image &im = sc->images[k];
+    for (int i = 0; i < n; ++i) {
+        V2 q = mk2(uv[2 * i], uv[2 * i + 1]);
+        V3 r = im.kind == IMG_COLOR ? image_color(im, q) : image_normal(im, q, Frame(mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2])));
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
+
 // camera matrices, row-major 4x4: sampleToCamera, cameraToWorld; + [invW, invH, near, far]
 void orc_camera(void *hp, int si, float *s2c, float *c2w, float *misc) {
     const Scene *sc; const Accel *ac; sub(hp, si, &sc, &ac);
@@ -190,12 +220,24 @@ void orc_bsdf_sample(int type, const float *params, int n, const float *wi, cons
     Bsdf b; b.type = type; b.albedo = mk3(params[0], params[1], params[2]); b.kd = b.albedo; b.alpha = params[3]; b.intIOR = params[4]; b.extIOR = params[5];
     b.ks = 1 - maxcoeff(b.kd);
     for (int i = 0; i < n; ++i) {
-        BsdfRec r; r.wi = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]); r.uv = mk2(0, 0); r.wo = mk3(0.f);
-        V3 w = bsdf_sample(b, r, mk2(sample[2 * i], sample[2 * i + 1]));
+        BsdfRec r; r.wi = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]); r.uv = mk2(0, 0); r.wo = mk3(0.f); r.albedo = b.albedo;
+        V3 w = bsdf_sample(b, r, mk2(sample[2 * i], sample[2 * i + 1]), mk2(sample[2 * i], sample[2 * i + 1]));
         float *o = out + 12 * (size_t) i;
         o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = r.wo.x; o[4] = r.wo.y; o[5] = r.wo.z;
         float pdf = r.wo_valid ? bsdf_pdf(b, r) : 0.f; V3 ev = r.wo_valid ? bsdf_eval(b, r) : mk3(0.f);
         o[6] = pdf; o[7] = ev.x; o[8] = ev.y; o[9] = ev.z; o[10] = r.isDelta ? 1.f : 0.f; o[11] = r.wo_valid ? 1.f : 0.f;
+    }
+}
+
+// ---- Subsurface::sampleDx alone: hit at p with shading normal nrm, sampler seeded (state, seq); out = probe o, d, mint, maxt, dx (10 floats)
+void orc_ss_sample_dx(const float *dmfp, int n, const float *p, const float *nrm, const uint64_t *states, const uint64_t *seqs, float *out) {
+    Bsdf b; b.type = BSDF_SUBSURFACE; b.dmfp = mk3(dmfp[0], dmfp[1], dmfp[2]);
+    for (int i = 0; i < n; ++i) {
+        Sampler s; s.rng.seed(states[i], seqs[i]);
+        Frame sh(mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]));
+        Ray pr; V2 dx; ss_sample_dx(b, mk3(p[3 * i], p[3 * i + 1], p[3 * i + 2]), sh, s, pr, dx);
+        float *o = out + 10 * (size_t) i;
+        o[0] = pr.o.x; o[1] = pr.o.y; o[2] = pr.o.z; o[3] = pr.d.x; o[4] = pr.d.y; o[5] = pr.d.z; o[6] = pr.mint; o[7] = pr.maxt; o[8] = dx.x; o[9] = dx.y;
     }
 }
 

@@ -5,7 +5,10 @@
 // Reference: src/bvh.cpp:404-463, src/mesh.cpp:40-168, src/sphere.cpp:42-152, src/arealight.cpp:41-116,
 //            src/diffuse.cpp:75-126, src/microfacet.cpp:55-161, src/dielectric.cpp:48-103, src/mirror.cpp:41-58,
 //            src/warp.cpp:59-63,221-244,263-267, src/pathMisIntegrator.cpp:18-168, src/render.cpp:72-198,
-//            src/block.cpp:38-195, src/independent.cpp:48-67, src/ttest.cpp:148-195, include/nori/dpdf.h:119-157.
+//            src/block.cpp:38-195, src/independent.cpp:48-67, src/ttest.cpp:148-195, include/nori/dpdf.h:119-157,
+//            src/subsurface.cpp:94-281 (+ the probe loop src/pathMisIntegrator.cpp:86-100),
+//            cuda/nori/imagetexture.cpp.cu:12-26, bumpMap.cpp.cu:10-27, normalMap.cpp.cu:10-24, mesh.cpp.cu:181-185,
+//            sphere.cpp.cu:145-149, src/imagetexture.cpp:49-77 (images and normal modifiers: parity unpinned).
 #pragma once
 #include "oscene.hpp"
 #include "obvh.hpp"
@@ -61,6 +64,52 @@ struct Sampler {
         return swap2d ? mk2(b, a) : mk2(a, b);
     }
 };
+
+// ---- images ---------------------------------------------------------------------------------------------
+// One lookup of a 4-channel texel grid; cu runs along the columns, rv along the rows, both in [0,1).  Bilinear restates
+// CUDA's tex2D for a normalised-coordinate, wrap-addressed, linearly filtered texture object (texel centres at
+// i + 0.5, blend weights with 8 fractional bits); nearest is the CPU renderer's truncating lookup.
+template <typename Texel>
+inline void image_lookup(const Image &im, float cu, float rv, Texel texel, float out[4]) {
+    const int W = im.cols, H = im.rows;
+    if (!im.bilinear) {
+        int col = std::min((int) (cu * (float) W), W - 1), row = std::min((int) (rv * (float) H), H - 1);
+        texel(row, col, out); return;
+    }
+    float xb = cu * (float) W - 0.5f, yb = rv * (float) H - 0.5f;
+    float fi = std::floor(xb), fj = std::floor(yb);
+    float a = std::floor((xb - fi) * 256.0f + 0.5f) * (1.0f / 256.0f), b = std::floor((yb - fj) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i0 = (int) fi, j0 = (int) fj; if (i0 < 0) i0 += W; if (j0 < 0) j0 += H;
+    int i1 = i0 + 1 == W ? 0 : i0 + 1, j1 = j0 + 1 == H ? 0 : j0 + 1;
+    float t00[4], t10[4], t01[4], t11[4];
+    texel(j0, i0, t00); texel(j0, i1, t10); texel(j1, i0, t01); texel(j1, i1, t11);
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    for (int c = 0; c < 4; ++c) out[c] = ((w00 * t00[c] + w10 * t10[c]) + w01 * t01[c]) + w11 * t11[c];
+}
+inline V2 image_coords(const Image &im, V2 uv) {          // imagetexture.cpp.cu:15-20
+    float x = (uv.x / im.scale.x) - im.delta.x, y = (uv.y / im.scale.y) - im.delta.y;
+    return mk2(x - std::floor(x), y - std::floor(y));
+}
+inline void image_rgba(const Image &im, float cu, float rv, float out[4]) {
+    image_lookup(im, cu, rv, [&](int r, int c, float *o) { const uint8_t *p = &im.rgba[((size_t) r * im.cols + c) * 4]; for (int k = 0; k < 4; ++k) o[k] = (float) p[k] / 255.0f; }, out);
+}
+inline float srgb_to_linear(float v) { return v <= 0.04045f ? v * (1.0f / 12.92f) : std::pow((v + 0.055f) * (1.0f / 1.055f), 2.4f); }   // src/common.cpp:208-222
+inline V3 image_color(const Image &im, V2 uv) {           // ImageTexture<Color3f>::eval
+    V2 c = image_coords(im, uv); float t[4]; image_rgba(im, c.y, c.x, t);
+    if (!im.bilinear) return mk3(t[0], t[1], t[2]);       // CPU variant: no colour-space conversion (src/imagetexture.cpp:49-77)
+    return mk3(srgb_to_linear(t[0]), srgb_to_linear(t[1]), srgb_to_linear(t[2]));
+}
+inline V3 image_normal(const Image &im, V2 uv, const Frame &fr) {      // BumpMap::eval / NormalMap::eval
+    V2 c = image_coords(im, uv); float t[4];
+    if (im.kind == IMG_BUMP) {
+        image_lookup(im, c.x, c.y, [&](int r, int cc, float *o) {
+            float x = (float) im.gx[(size_t) r * im.cols + cc] / 32767.0f, y = (float) im.gy[(size_t) r * im.cols + cc] / 32767.0f;
+            o[0] = x < -1.0f ? -1.0f : x; o[1] = y < -1.0f ? -1.0f : y; o[2] = o[3] = 0.f; }, t);
+        return normalized((fr.n + t[0] * cross(fr.n, fr.s)) - t[1] * cross(fr.n, fr.t));
+    }
+    image_rgba(im, c.y, c.x, t);
+    return fr.toWorld(normalized(mk3((2.0f * t[0]) - 1.0f, (2.0f * t[1]) - 1.0f, t[2])));
+}
 
 struct Accel {
     const Scene *scene = nullptr;
@@ -123,6 +172,11 @@ struct Accel {
 
     // src/mesh.cpp:123-168, src/sphere.cpp:115-141
     void set_hit_information(uint32_t f, const Ray &ray, Intersection &its) const {
+        set_hit_information_base(f, ray, its);
+        const Shape &m = scene->shapes[its.shape];
+        if (m.normal_tex >= 0) its.sh = Frame(image_normal(scene->images[m.normal_tex], its.uv, its.sh));   // cuda/nori/mesh.cpp.cu:181-185
+    }
+    void set_hit_information_base(uint32_t f, const Ray &ray, Intersection &its) const {
         const Shape &m = scene->shapes[its.shape];
         if (m.type == SHAPE_SPHERE) {
             its.p = ray.o + its.t * ray.d;
@@ -224,7 +278,13 @@ inline V3 square_to_uniform_triangle(V2 s) {
 }
 
 // ---- BSDFs ----------------------------------------------------------------------------------------------
-struct BsdfRec { V3 wi, wo; V2 uv; bool isDelta = false; bool wo_valid = false; };
+struct BsdfRec { V3 wi, wo; V2 uv; bool isDelta = false; bool wo_valid = false; V3 albedo; };   // albedo: Texture::eval(uv), filled by the integrator
+
+inline float ss_fresnel_transmission(const Bsdf &b, const BsdfRec &r) {     // src/subsurface.cpp:173-178
+    float Ft_i = 1.0f - fresnel(r.wi.z, b.extIOR, b.intIOR);
+    float Ft_o = 1.0f - fresnel(r.wo.z, b.extIOR, b.intIOR);
+    return Ft_i * Ft_o;
+}
 
 inline float beckmann_D(const Bsdf &b, V3 m) {             // src/microfacet.cpp:55-61
     float temp = tan_theta(m) / b.alpha, ct = m.z, ct2 = ct * ct;
@@ -243,7 +303,9 @@ inline V3 bsdf_eval(const Bsdf &b, const BsdfRec &r) {
     switch (b.type) {
     case BSDF_DIFFUSE:                                       // src/diffuse.cpp:75-86
         if (r.wi.z <= 0 || r.wo.z <= 0) return mk3(0.f);
-        return b.albedo * kInvPi;
+        return r.albedo * kInvPi;
+    case BSDF_SUBSURFACE:                                    // src/subsurface.cpp:99-104
+        return (ss_fresnel_transmission(b, r) * r.albedo) * kInvPi;
     case BSDF_MICROFACET: {                                  // src/microfacet.cpp:87-100
         V3 wh = normalized(r.wi + r.wo);
         float G = smith_g1(b, r.wi, wh) * smith_g1(b, r.wo, wh);
@@ -260,6 +322,7 @@ inline V3 bsdf_eval(const Bsdf &b, const BsdfRec &r) {
 inline float bsdf_pdf(const Bsdf &b, const BsdfRec &r) {
     switch (b.type) {
     case BSDF_DIFFUSE:                                       // src/diffuse.cpp:89-105
+    case BSDF_SUBSURFACE:                                    // src/subsurface.cpp:181-197
         if (r.wi.z <= 0 || r.wo.z <= 0) return 0.0f;
         return kInvPi * r.wo.z;
     case BSDF_MICROFACET: {                                  // src/microfacet.cpp:103-117
@@ -274,13 +337,17 @@ inline float bsdf_pdf(const Bsdf &b, const BsdfRec &r) {
 }
 // sample(): returns the importance weight; sets r.wo / r.isDelta.  r.wo_valid=false marks the reference's
 // early-return branches that leave bRec.wo uninitialised (src/diffuse.cpp:111-112, src/mirror.cpp:42-43).
-inline V3 bsdf_sample(const Bsdf &b, BsdfRec &r, V2 sample) {
+inline V3 bsdf_sample(const Bsdf &b, BsdfRec &r, V2 sample, V2 sample2 = mk2(0.f, 0.f)) {
     r.wo_valid = true;
     switch (b.type) {
     case BSDF_DIFFUSE:                                       // src/diffuse.cpp:109-126
         if (r.wi.z <= 0) { r.wo_valid = false; return mk3(0.f); }
         r.wo = square_to_cosine_hemisphere(sample);
-        return b.albedo;
+        return r.albedo;
+    case BSDF_SUBSURFACE:                                    // src/subsurface.cpp:253-281 (uses the SECOND sample)
+        r.wo = square_to_cosine_hemisphere(sample2);
+        if (r.wi.z <= 0 || r.wo.z <= 0) return mk3(0.f);
+        return ss_fresnel_transmission(b, r) * r.albedo;
     case BSDF_MICROFACET: {                                  // src/microfacet.cpp:121-161
         if (sample.x < b.ks) {
             sample.x /= b.ks;
@@ -387,7 +454,49 @@ struct PathStats { uint64_t closest = 0, shadow = 0, bounces = 0; TraceCounters 
 //  * when sample() returns a zero weight the path is ended: the reference multiplies the throughput by zero and
 //    keeps bouncing (with an uninitialised wo for the two early-return branches) until roulette/escape, adding
 //    exact zeros.  Only the amount of random numbers consumed afterwards differs.
-//  * subsurface (probe rays) is not restated in this round.
+//  * the probe loop of a subsurface hit (:88-90) is unbounded in the reference; here a path is dropped after
+//    kProbeTries unsuccessful probes (never reached on closed meshes).
+// ---- Subsurface::sampleDx and its helpers (src/subsurface.cpp:94-150,199-249) ---------------------------
+#ifdef ORC_SS_EXP_DOUBLE
+#define SSEXP(x) std::exp((double) (x))
+#else
+#define SSEXP(x) std::exp(x)
+#endif
+inline float color_norm(V3 c) { return std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z); }
+inline float ss_cdf(float r, float cs, float cd) { float rsd = -r * cs / cd; return 1.0f - 0.25f * SSEXP(rsd) - 0.75f * SSEXP(rsd / 3.0f); }
+inline float ss_cdf_derivative(float r, float cs, float cd) { float sd = cs / cd; float rsd = -r * sd; return sd * 0.25f * (SSEXP(rsd) + SSEXP(rsd / 3.0f)); }
+inline V2 ss_sample_disk(V2 sample2, float cs, float cd) {
+    float sample = sample2.x;
+    float sdInv = cd / cs;
+    float r0 = -std::log((1.0f - sample) * 4.0 / 3.0) * 3.0f * sdInv;      // double until the assignment
+    float r1;                                                               // (the reference's r1 / err0 / err1 never influence r0)
+    for (int i = 0; i < 3; ++i) {
+        float f = (ss_cdf(r0, cs, cd) - sample);
+        float df = ss_cdf_derivative(r0, cs, cd);
+        r1 = r0 - f / df;
+        r0 = r1;
+    }
+    float theta = 2.0f * kPi * sample2.y;                                   // M_PI is a float literal in Nori (include/nori/common.h:56)
+    return mk2((float) (r0 * u_cos(theta)), (float) (r0 * u_sin(theta)));
+}
+// Subsurface::sampleDx: one probe ray (direction picked from the shading frame, origin offset by the sampled disk point)
+inline void ss_sample_dx(const Bsdf &bsdf, V3 p, const Frame &sh, Sampler &smp, Ray &probe, V2 &dx) {
+    const float cs = color_norm(mk3(1.0f)), cd = color_norm(bsdf.dmfp);
+    float thres = smp.next1D();
+    float k = 0.5f / 4.0f;
+    if (thres < 0.5f) probe.d = -sh.n;
+    else if (thres < 0.5f + k) probe.d = sh.t;
+    else if (thres < 0.5f + 2 * k) probe.d = -sh.t;
+    else if (thres < 0.5f + 3 * k) probe.d = sh.s;
+    else probe.d = -sh.s;
+    dx = ss_sample_disk(smp.next2D(), cs, cd);
+    Frame frame(-probe.d);
+    probe.o = p + frame.toWorld(mk3(dx.x, dx.y, 0));
+    float eps = 1e-3;
+    probe.mint = -eps; probe.maxt = std::sqrt(dx.x * dx.x + dx.y * dx.y) + eps; probe.update();
+}
+static const int kProbeTries = 4096;
+
 inline V3 path_mis_li(const Accel &acc, Sampler &smp, const Ray &_ray, PathStats *st = nullptr, bool bsdf_second_first = true) {
     const Scene &sc = *acc.scene;
     Ray ray = _ray;
@@ -414,13 +523,24 @@ inline V3 path_mis_li(const Accel &acc, Sampler &smp, const Ray &_ray, PathStats
 
         const Bsdf &bsdf = mesh.bsdf;
         BsdfRec br; br.wi = its.sh.toLocal(-ray.d); br.uv = its.uv;
+        br.albedo = bsdf.albedo_tex >= 0 ? image_color(sc.images[bsdf.albedo_tex], its.uv) : bsdf.albedo;
+        Intersection its_out = its;                                              // BSDF::sampleDx default (include/nori/bsdf.h:97)
+        if (bsdf.type == BSDF_SUBSURFACE) {                                      // :86-95, src/subsurface.cpp:199-249
+            bool found = false;
+            for (int tries = 0; tries < kProbeTries && !found; ++tries) {
+                Ray probe; V2 dx;
+                ss_sample_dx(bsdf, its.p, its.sh, smp, probe, dx);
+                if (st) st->closest++;
+                found = acc.ray_intersect(probe, its_out, false, its.shape, st ? &st->tc : nullptr);
+            }
+            if (!found) break;
+        }
         V2 s1, s2;
         if (bsdf_second_first) { s2 = smp.next2D(); s1 = smp.next2D(); } else { s1 = smp.next2D(); s2 = smp.next2D(); }
-        (void) s2;
-        V3 f = bsdf_sample(bsdf, br, s1);
+        V3 f = bsdf_sample(bsdf, br, s1, s2);
         last_bsdf_pdf = br.wo_valid ? bsdf_pdf(bsdf, br) : 0.0f;
         lastBsdfDelta = br.isDelta;
-        V3 next_dir = br.wo_valid ? normalized(its.sh.toWorld(br.wo)) : mk3(0.f);
+        V3 next_dir = br.wo_valid ? normalized(its_out.sh.toWorld(br.wo)) : mk3(0.f);
 
         float pick = smp.next1D();
         if (!br.isDelta) {
@@ -428,22 +548,22 @@ inline V3 path_mis_li(const Accel &acc, Sampler &smp, const Ray &_ray, PathStats
             size_t index = std::min((size_t) std::floor(n * pick), n - 1);
             const Emitter &light = sc.emitters[index];
             const Shape &lshape = sc.shapes[light.shape];
-            EmitterRec q; q.ref = its.p;
+            EmitterRec q; q.ref = its_out.p;
             V3 liLoc = emitter_sample(light, lshape, q, smp.next2D());
             V3 light_dir = q.wi;
             Intersection tmp;
             if (st) st->shadow++;
             if (!acc.ray_intersect(q.shadowRay, tmp, true, -1, st ? &st->tc : nullptr)) {
-                br.wo = its.sh.toLocal(light_dir);
+                br.wo = its_out.sh.toLocal(light_dir);
                 float bpdf = bsdf_pdf(bsdf, br);
                 float lpdf = emitter_pdf(lshape, q);
                 float wem = lpdf / (lpdf + bpdf);
-                float cosS = dot(normalized(light_dir), normalized(its.sh.n));
+                float cosS = dot(normalized(light_dir), normalized(its_out.sh.n));
                 if (wem > 0) li = li + ((((t * wem) * liLoc) * bsdf_eval(bsdf, br)) * std::fabs(cosS)) * (float) n;
             }
         }
         if (!br.wo_valid || is_zero(f)) break;
-        ray.d = next_dir; ray.o = its.p; ray.mint = 1e-3; ray.maxt = kInf; ray.update();
+        ray.d = next_dir; ray.o = its_out.p; ray.mint = 1e-3; ray.maxt = kInf; ray.update();
         t = t * f;
     }
     return li;

@@ -6,7 +6,9 @@
 //            src/mesh.cpp:30-38,75-81,170-182 (area CDF, surfaceArea, per-triangle bbox / centroid),
 //            src/sphere.cpp:30-40, src/perspective.cpp:34-88, src/scene.cpp:62-99 (child registration order),
 //            src/diffuse.cpp:31-72, src/microfacet.cpp:28-50, src/dielectric.cpp:28-34, src/arealight.cpp:29-31,
-//            src/independent.cpp:35-37, src/ttest.cpp:60-77.
+//            src/independent.cpp:35-37, src/ttest.cpp:60-77, src/subsurface.cpp:32-50,
+//            cuda/nori/imagetexture.cpp.cu:29-52, cuda/nori/bumpMap.cpp.cu:31-115, cuda/nori/normalMap.cpp.cu:28-97 (images:
+//            "parity unpinned" — the reference decodes with OpenCV, which is not available; see oracle/README.md).
 #pragma once
 #include "omath.hpp"
 #include "oxml.hpp"
@@ -52,7 +54,8 @@ inline float deg_to_rad(float v) { return v * (kPi / 180.0f); }
 // ---- property list ---------------------------------------------------------------------------------------
 struct Props {
     std::map<std::string, float> f; std::map<std::string, int> i; std::map<std::string, std::string> s;
-    std::map<std::string, V3> v; std::map<std::string, Transform> t; std::map<std::string, bool> b;
+    std::map<std::string, V3> v; std::map<std::string, Transform> t; std::map<std::string, bool> b; std::map<std::string, V2> v2;
+    V2 getv2(const char *k, V2 d) const { auto it = v2.find(k); return it == v2.end() ? d : it->second; }
     float getf(const char *k, float d) const { auto it = f.find(k); return it == f.end() ? d : it->second; }
     int geti(const char *k, int d) const { auto it = i.find(k); return it == i.end() ? d : it->second; }
     V3 getv(const char *k, V3 d) const { auto it = v.find(k); return it == v.end() ? d : it->second; }
@@ -63,12 +66,23 @@ struct Props {
 };
 
 // ---- objects ---------------------------------------------------------------------------------------------
-enum BsdfType { BSDF_DIFFUSE = 0, BSDF_MICROFACET = 1, BSDF_DIELECTRIC = 2, BSDF_MIRROR = 3 };
+enum BsdfType { BSDF_DIFFUSE = 0, BSDF_MICROFACET = 1, BSDF_DIELECTRIC = 2, BSDF_MIRROR = 3, BSDF_SUBSURFACE = 4 };
 struct Bsdf {
     int type = BSDF_DIFFUSE;
-    V3 albedo = mk3(0.5f);                 // diffuse (src/diffuse.cpp:65-72 default)
+    V3 albedo = mk3(0.5f);                 // diffuse / subsurface (src/diffuse.cpp:65-72 default)
+    int albedo_tex = -1;                   // index into Scene::images when the albedo is an image_color texture
     float alpha = 0.1f, intIOR = 1.5046f, extIOR = 1.000277f, ks = 0.5f;
     V3 kd = mk3(0.5f);
+    V3 dmfp = mk3(0.1f);                   // subsurface (src/subsurface.cpp:44-46); s = 1 (:91)
+};
+// An image as the CUDA fork uploads it: RGBA bytes (colour, normal map) or the two 16-bit Sobel gradients (bump map)
+enum ImageKind { IMG_COLOR = 0, IMG_BUMP = 1, IMG_NORMAL = 2 };
+struct Image {
+    int kind = IMG_COLOR; bool bilinear = true;
+    int cols = 0, rows = 0;
+    std::vector<uint8_t> rgba;             // IMG_COLOR / IMG_NORMAL: 4 per texel
+    std::vector<int16_t> gx, gy;           // IMG_BUMP
+    V2 scale = mk2(1.f, 1.f), delta = mk2(0.f, 0.f);
 };
 struct Emitter { V3 radiance; int shape = -1; };
 
@@ -80,6 +94,7 @@ struct Shape {
     BBox bbox;
     V3 center = mk3(0.f); float radius = 1.f;                            // sphere
     Bsdf bsdf; bool has_bsdf = false;
+    int normal_tex = -1;                                                 // index into Scene::images (bump_map / normal_map)
     int emitter = -1;                                                    // index into Scene::emitters
     std::vector<float> cdf; float cdf_sum = 0, cdf_norm = 0;             // DiscretePDF (include/nori/dpdf.h)
     uint32_t prim_count() const { return type == SHAPE_MESH ? (uint32_t) (F.size() / 3) : 1u; }
@@ -152,6 +167,7 @@ struct Camera {
 struct Scene {
     std::vector<Shape> shapes;
     std::vector<Emitter> emitters;
+    std::vector<Image> images;
     Camera camera;
     int sample_count = 1;
     std::string integrator;
@@ -285,6 +301,9 @@ inline void parse_props(const XmlNode &node, Props &pl) {
         else if (t == "integer") pl.i[ch.attr("name")] = to_int(ch.attr("value"));
         else if (t == "string") pl.s[ch.attr("name")] = ch.attr("value");
         else if (t == "boolean") { std::string v = ch.attr("value"); for (auto &c : v) c = (char) tolower(c); pl.b[ch.attr("name")] = (v == "true"); }
+        else if ((t == "point" || t == "vector") && tokenize(ch.attr("value")).size() == 2) {      // src/parser.cpp:242-266
+            auto tk = tokenize(ch.attr("value")); pl.v2[ch.attr("name")] = mk2(to_float(tk[0]), to_float(tk[1]));
+        }
         else if (t == "color" || t == "point" || t == "vector") pl.v[ch.attr("name")] = to_v3(ch.attr("value"));
         else if (t == "transform") {
             Affine a; a.set_identity();
@@ -293,10 +312,67 @@ inline void parse_props(const XmlNode &node, Props &pl) {
         }
     }
 }
-inline Bsdf parse_bsdf(const XmlNode &n) {
+// ---- images: binary PNM (P5/P6); for other formats the pre-decoded "<file>.ppm" / "<file>.pgm" next to it ----
+inline bool read_pnm(const std::string &path, int &cols, int &rows, int &ch, std::vector<uint8_t> &data) {
+    std::ifstream f(path, std::ios::binary); if (!f) return false;
+    std::string magic; f >> magic; if (magic != "P5" && magic != "P6") return false;
+    auto next_int = [&]() { for (;;) { f >> std::ws; if (f.peek() == '#') { std::string l; std::getline(f, l); } else break; } int v = 0; f >> v; return v; };
+    cols = next_int(); rows = next_int(); int maxv = next_int(); f.get();
+    if (cols <= 0 || rows <= 0 || maxv != 255) throw std::runtime_error("oracle: unsupported PNM " + path);
+    ch = magic == "P6" ? 3 : 1; data.resize((size_t) cols * rows * ch);
+    f.read((char *) data.data(), (std::streamsize) data.size());
+    if ((size_t) f.gcount() != data.size()) throw std::runtime_error("oracle: truncated PNM " + path);
+    return true;
+}
+inline void load_image_file(const std::string &path, int &cols, int &rows, int &ch, std::vector<uint8_t> &data) {
+    if (read_pnm(path, cols, rows, ch, data) || read_pnm(path + ".ppm", cols, rows, ch, data) || read_pnm(path + ".pgm", cols, rows, ch, data)) return;
+    throw std::runtime_error("Image " + path + " could not be found!");
+}
+inline Image load_image(const XmlNode &n, const std::string &dir, int kind) {
+    Props pl; parse_props(n, pl);
+    Image im; im.kind = kind; im.delta = pl.getv2("delta", mk2(0.f, 0.f)); im.scale = pl.getv2("scale", mk2(1.f, 1.f));
+    im.bilinear = pl.gets("lookup", "bilinear") != "nearest";
+    int ch; std::vector<uint8_t> px; load_image_file(dir + "/" + pl.gets("filename"), im.cols, im.rows, ch, px);
+    const size_t N = (size_t) im.cols * im.rows;
+    if (kind != IMG_BUMP) {
+        im.rgba.resize(N * 4);
+        for (size_t i = 0; i < N; ++i) for (int c = 0; c < 4; ++c) im.rgba[4 * i + c] = c == 3 ? 255 : (ch == 3 ? px[3 * i + c] : px[i]);
+        return im;
+    }
+    // grey image, then cv::Sobel(CV_16S, ksize 3, scale = height, delta = grad_delta, BORDER_REFLECT_101) in x and in y
+    float height = pl.getf("height", 5), grad_delta = pl.getf("grad_delta", 0);
+    std::vector<int> g(N);
+    for (size_t i = 0; i < N; ++i) g[i] = ch == 1 ? px[i] : ((px[3 * i] * 4899 + px[3 * i + 1] * 9617 + px[3 * i + 2] * 1868 + 8192) >> 14);
+    auto refl = [](int i, int n) { if (n == 1) return 0; if (i < 0) i = -i; if (i >= n) i = 2 * n - 2 - i; return i; };
+    auto at = [&](int r, int c) { return g[(size_t) refl(r, im.rows) * im.cols + refl(c, im.cols)]; };
+    auto sat16 = [](float v) { long q = lrintf(v); return (int16_t) std::min(32767l, std::max(-32768l, q)); };
+    im.gx.resize(N); im.gy.resize(N);
+    for (int r = 0; r < im.rows; ++r) for (int c = 0; c < im.cols; ++c) {
+        int sx = 0, sy = 0; const int w3[3] = {1, 2, 1};
+        for (int k = -1; k <= 1; ++k) { sx += w3[k + 1] * (at(r + k, c + 1) - at(r + k, c - 1)); sy += w3[k + 1] * (at(r + 1, c + k) - at(r - 1, c + k)); }
+        im.gx[(size_t) r * im.cols + c] = sat16((float) sx * height + grad_delta); im.gy[(size_t) r * im.cols + c] = sat16((float) sy * height + grad_delta);
+    }
+    return im;
+}
+
+inline Bsdf parse_bsdf(const XmlNode &n, const std::string &dir, std::vector<Image> &images) {
     Props pl; parse_props(n, pl);
     Bsdf b; std::string type = n.attr("type");
-    if (type == "diffuse") { b.type = BSDF_DIFFUSE; b.albedo = pl.getv("albedo", mk3(0.5f)); }
+    auto albedo = [&]() {                  // colour property or <texture name="albedo"> child (src/diffuse.cpp:31-63)
+        bool has = pl.hasv("albedo"); b.albedo = pl.getv("albedo", mk3(0.5f));
+        for (auto &ch : n.children) if (ch->name == "texture") {
+            if (std::string(ch->attr("name")) != "albedo") throw std::runtime_error("The name of this texture does not match any field!");
+            if (has) throw std::runtime_error("There is already an albedo defined!");
+            has = true; std::string tt = ch->attr("type");
+            if (tt == "constant_color") { Props tp; parse_props(*ch, tp); b.albedo = tp.getv("value", mk3(0.f)); }
+            else if (tt == "image_color") { b.albedo_tex = (int) images.size(); images.push_back(load_image(*ch, dir, IMG_COLOR)); }
+            else throw std::runtime_error("oracle: unsupported texture type \"" + tt + "\"");
+        }
+    };
+    if (type == "diffuse") { b.type = BSDF_DIFFUSE; albedo(); }
+    else if (type == "subsurface") {       // src/subsurface.cpp:32-50
+        b.type = BSDF_SUBSURFACE; albedo(); b.intIOR = pl.getf("intIOR", 1.3046f); b.extIOR = pl.getf("extIOR", 1.000277f); b.dmfp = pl.getv("dmfp", mk3(0.1f));
+    }
     else if (type == "microfacet") {
         b.type = BSDF_MICROFACET; b.alpha = pl.getf("alpha", 0.1f); b.intIOR = pl.getf("intIOR", 1.5046f);
         b.extIOR = pl.getf("extIOR", 1.000277f); b.kd = pl.getv("kd", mk3(0.5f)); b.ks = 1 - maxcoeff(b.kd);
@@ -331,7 +407,13 @@ inline Scene parse_scene(const XmlNode &node, const std::string &dir) {
             } else throw std::runtime_error("oracle: unsupported mesh type \"" + type + "\"");
             bool is_emitter = false; Emitter em;
             for (auto &sub : ch.children) {
-                if (sub->name == "bsdf") { if (sh.has_bsdf) throw std::runtime_error("Shape: tried to register multiple BSDF instances!"); sh.bsdf = parse_bsdf(*sub); sh.has_bsdf = true; }
+                if (sub->name == "bsdf") { if (sh.has_bsdf) throw std::runtime_error("Shape: tried to register multiple BSDF instances!"); sh.bsdf = parse_bsdf(*sub, dir, sc.images); sh.has_bsdf = true; }
+                else if (sub->name == "normalModifier") {
+                    if (sh.normal_tex >= 0) throw std::runtime_error("Shape: tried to register multiple Normal modifier instances!");
+                    std::string mt = sub->attr("type");
+                    if (mt != "bump_map" && mt != "normal_map") throw std::runtime_error("oracle: unsupported normalModifier type \"" + mt + "\"");
+                    sh.normal_tex = (int) sc.images.size(); sc.images.push_back(load_image(*sub, dir, mt == "bump_map" ? IMG_BUMP : IMG_NORMAL));
+                }
                 else if (sub->name == "emitter") {
                     if (is_emitter) throw std::runtime_error("Shape: tried to register multiple Emitter instances!");
                     Props ep; parse_props(*sub, ep);

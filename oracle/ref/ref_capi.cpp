@@ -246,6 +246,7 @@ void ref_bsdf_sample(int type, const float *params, int n, const float *wi, cons
     if (type == 0) { pl.setColor("albedo", Color3f(params[0], params[1], params[2])); }
     else if (type == 1) { name = "microfacet"; pl.setColor("kd", Color3f(params[0], params[1], params[2])); pl.setFloat("alpha", params[3]); pl.setFloat("intIOR", params[4]); pl.setFloat("extIOR", params[5]); }
     else if (type == 2) { name = "dielectric"; pl.setFloat("intIOR", params[4]); pl.setFloat("extIOR", params[5]); }
+    else if (type == 4) { name = "subsurface"; pl.setColor("albedo", Color3f(params[0], params[1], params[2])); pl.setFloat("intIOR", params[4]); pl.setFloat("extIOR", params[5]); }
     else name = "mirror";
     BSDF *b = static_cast<BSDF *>(NoriObjectFactory::createInstance(name, pl));
     b->activate();
@@ -253,12 +254,29 @@ void ref_bsdf_sample(int type, const float *params, int n, const float *wi, cons
     for (int i = 0; i < n; ++i) {
         BSDFQueryRecord r(Vector3f(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]));
         r.measure = ESolidAngle; r.uv = Point2f(0.f, 0.f); r.wo = Vector3f(0.f, 0.f, 0.f);
-        Color3f w = b->sample(r, its, Point2f(sample[2 * i], sample[2 * i + 1]), Point2f(0.f, 0.f));
+        Color3f w = b->sample(r, its, Point2f(sample[2 * i], sample[2 * i + 1]), type == 4 ? Point2f(sample[2 * i], sample[2 * i + 1]) : Point2f(0.f, 0.f));
         float *o = out + 12 * (size_t) i;
         bool wo_valid = !((type == 0 || type == 3) && r.wi.z() <= 0);
         o[0] = w.r(); o[1] = w.g(); o[2] = w.b(); o[3] = r.wo.x(); o[4] = r.wo.y(); o[5] = r.wo.z();
         float pdf = wo_valid ? b->pdf(r) : 0.f; Color3f ev = wo_valid ? b->eval(r) : Color3f(0.f);
         o[6] = pdf; o[7] = ev.r(); o[8] = ev.g(); o[9] = ev.b(); o[10] = r.isDelta ? 1.f : 0.f; o[11] = wo_valid ? 1.f : 0.f;
+    }
+    delete b;
+}
+// Subsurface::sampleDx alone (src/subsurface.cpp:199-249): same layout as orc_ss_sample_dx
+void ref_ss_sample_dx(const float *dmfp, int n, const float *p, const float *nrm, const uint64_t *states, const uint64_t *seqs, float *out) {
+    PropertyList pl; pl.setColor("dmfp", Color3f(dmfp[0], dmfp[1], dmfp[2]));
+    BSDF *b = static_cast<BSDF *>(NoriObjectFactory::createInstance("subsurface", pl));
+    b->activate();
+    for (int i = 0; i < n; ++i) {
+        SeededSampler s(states[i], seqs[i]);
+        Intersection its; its.p = Point3f(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+        its.shFrame = Frame(Vector3f(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2])); its.geoFrame = its.shFrame;
+        BSDFQueryRecord r(Vector3f(0.f, 0.f, 1.f));
+        b->sampleDx(r, its, s);
+        float *o = out + 10 * (size_t) i;
+        o[0] = r.probeRay.o.x(); o[1] = r.probeRay.o.y(); o[2] = r.probeRay.o.z(); o[3] = r.probeRay.d.x(); o[4] = r.probeRay.d.y(); o[5] = r.probeRay.d.z();
+        o[6] = r.probeRay.mint; o[7] = r.probeRay.maxt; o[8] = r.dx.x(); o[9] = r.dx.y();
     }
     delete b;
 }

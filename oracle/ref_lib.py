@@ -111,6 +111,17 @@ def bsdf_sample(btype, params, wi, sample):
     return out
 
 
+def ss_sample_dx(dmfp, p, nrm, states, seqs):
+    """Subsurface::sampleDx alone: rows of probe o, d, mint, maxt, dx"""
+    p = np.ascontiguousarray(p, np.float32)
+    nrm = np.ascontiguousarray(nrm, np.float32)
+    st = np.ascontiguousarray(states, np.uint64)
+    sq = np.ascontiguousarray(seqs, np.uint64)
+    out = np.zeros((len(p), 10), np.float32)
+    lib().ref_ss_sample_dx(_p(np.ascontiguousarray(dmfp, np.float32)), len(p), _p(p), _p(nrm), _p(st), _p(sq), _p(out))
+    return out
+
+
 def pcg32(state, seq, n):
     out = np.zeros(n, np.uint32)
     lib().ref_pcg32(C.c_uint64(state), C.c_uint64(seq), n, _p(out))

@@ -76,6 +76,31 @@ class OracleScene:
             d.update(V=V, N=N, UV=UV, F=F, cdf=cdf)
         return d
 
+    def images(self, si=0):
+        """the scene's images as the device reads them: dicts of kind, lookup, cols, rows, scale, delta, texels (bytes)"""
+        out = []
+        for k in range(lib().orc_image_count(self.h, si)):
+            info = (C.c_int * 4)()
+            xf = np.zeros(4, np.float32)
+            lib().orc_image_get(self.h, si, k, info, _p(xf), None)
+            tex = np.zeros(info[2] * info[3] * 4, np.uint8)
+            lib().orc_image_get(self.h, si, k, info, _p(xf), _p(tex))
+            out.append(dict(kind=info[0], lookup=info[1], cols=info[2], rows=info[3], scale=xf[0:2].copy(), delta=xf[2:4].copy(), texels=tex))
+        return out
+
+    def shape_images(self, s, si=0):
+        out = (C.c_int * 2)()
+        dm = np.zeros(3, np.float32)
+        lib().orc_shape_images(self.h, si, s, out, _p(dm))
+        return dict(albedo_tex=out[0], normal_tex=out[1], dmfp=dm)
+
+    def image_eval(self, k, uv, nrm=None, si=0):
+        uv = np.ascontiguousarray(uv, np.float32)
+        nrm = None if nrm is None else np.ascontiguousarray(nrm, np.float32)
+        out = np.zeros((len(uv), 3), np.float32)
+        lib().orc_image_eval(self.h, si, k, len(uv), _p(uv), _p(nrm), _p(out))
+        return out
+
     def camera(self, si=0):
         s2c = np.zeros((4, 4), np.float32)
         c2w = np.zeros((4, 4), np.float32)
@@ -155,6 +180,17 @@ class OracleScene:
         v = C.c_double()
         lib().orc_test_run_one(self.h, i, C.c_uint64(state), C.c_uint64(seq), n, C.byref(m), C.byref(v))
         return m.value, v.value
+
+
+def ss_sample_dx(dmfp, p, nrm, states, seqs):
+    """Subsurface::sampleDx alone: rows of probe o, d, mint, maxt, dx"""
+    p = np.ascontiguousarray(p, np.float32)
+    nrm = np.ascontiguousarray(nrm, np.float32)
+    st = np.ascontiguousarray(states, np.uint64)
+    sq = np.ascontiguousarray(seqs, np.uint64)
+    out = np.zeros((len(p), 10), np.float32)
+    lib().orc_ss_sample_dx(_p(np.ascontiguousarray(dmfp, np.float32)), len(p), _p(p), _p(nrm), _p(st), _p(sq), _p(out))
+    return out
 
 
 def pcg32(state, seq, n):

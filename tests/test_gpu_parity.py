@@ -16,7 +16,10 @@ SCENE_XML = {
     "table": "table/table_path_mis.xml",
     "table_microfacet": "table/table_path_mis_microfacet.xml",
     "dragon": "proj/dragon-diffuse.xml",
+    "cbox_subsurface": "proj/cbox_subsurface.xml",       # subsurface shapes: probe rays, masked traversal (EXT kernels)
 }
+# scenes with images (no reference fixtures: the reference needs OpenCV to load them; the oracle's restatement is the checker)
+IMAGE_XML = {"texture_bump": "proj/textureAndBump.xml", "normal_map": "proj/normal.xml"}
 
 
 def hits_as_u32(h):
@@ -30,7 +33,7 @@ def loaded():
     def get(name, W, H):
         key = (name, W, H)
         if key not in cache:
-            hs = NH.HostScene(os.path.join(SCENES, SCENE_XML[name]), W, H, 1)
+            hs = NH.HostScene(os.path.join(SCENES, {**SCENE_XML, **IMAGE_XML}[name]), W, H, 1)
             cache[key] = (hs, hs.preprocess())
         return cache[key]
     yield get
@@ -132,7 +135,7 @@ def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
     assert np.allclose(parts, whole, rtol=1e-4, atol=1e-5)                    # fp32 atomics: order differs, values do not
 
 
-@pytest.mark.parametrize("name", ["cbox_mirror_microfacet", "table", "dragon"])
+@pytest.mark.parametrize("name", ["cbox_mirror_microfacet", "table", "dragon", "cbox_subsurface", "texture_bump"])
 def test_wavefront_and_single_kernel_pipelines_agree(name):
     """The staged pipeline (shade / shadow / extend kernels over a slot pool) and the single persistent kernel run the
     same per-sample arithmetic; only the fp32 atomic summation order into the film differs.  A small slot pool forces
@@ -148,7 +151,7 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
     for env in configs:
         os.environ.update(env)
         try:
-            hs = NH.HostScene(os.path.join(SCENES, SCENE_XML[name]), W, H, spp)
+            hs = NH.HostScene(os.path.join(SCENES, {**SCENE_XML, **IMAGE_XML}[name]), W, H, spp)
             ctx = hs.preprocess()
         finally:
             for k in env:
@@ -162,6 +165,60 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
         for k in ("camera_samples", "closest_rays", "shadow_rays", "invalid_samples"):
             assert st[k] == stats[0][k], (k, st[k], stats[0][k])
     assert stats[0]["camera_samples"] == W * H * spp and stats[0]["iterations"] > 10
+
+
+@pytest.mark.parametrize("name", list(IMAGE_XML))
+def test_images_and_normal_modifiers_against_oracle(name, loaded):
+    """image_color albedo, bump_map and normal_map (cuda/nori/imagetexture.cpp.cu, bumpMap.cpp.cu, normalMap.cpp.cu) on a
+    sphere and a mesh.  Texel decode is parity-unpinned; lookup, modifier and integrator are checked against
+    the oracle on the same texels.  Sphere uv goes through acos/atan2, so a lookup can land on the neighbouring texel
+    weight: compared with a tolerance, not bitwise."""
+    W, H, spp = 64, 48, 16
+    hs, ctx = loaded(name, W, H)
+    o = O.OracleScene(os.path.join(SCENES, IMAGE_XML[name]), W, H, spp)
+    rng = np.random.default_rng(9)
+    ps = (rng.random((6000, 2)) * [W, H]).astype(np.float32)
+    rays = o.camera_rays(ps)
+    assert np.array_equal(ctx.camera_rays(ps), rays)
+    hits, full = ctx.trace(rays, full=True)
+    ohits, ofull = o.trace(rays, full=True)
+    assert np.array_equal(hits["prim"], ohits[:, 0]) and np.array_equal(hits["t"].view(np.uint32), ohits[:, 1])   # prim, t bit-exact
+    assert np.abs(full[:, 0:5] - ofull[:, 0:5]).max() < 1e-5                                                      # p, uv
+    dn = np.abs(full[:, 5:8] - ofull[:, 5:8]).max(1)                          # shading normal AFTER the modifier
+    assert (dn < 1e-3).mean() > 0.995 and np.allclose(np.linalg.norm(full[hits["prim"] != NH.MISS, 5:8], axis=1), 1, atol=1e-5)
+    mod = np.abs(ofull[:, 5:8] - ofull[:, 8:11]).max(1) > 1e-3                # rays whose normal the modifier changed
+    assert mod.mean() > 0.05, mod.mean()
+    n = 4096
+    st = np.arange(n, dtype=np.uint64)
+    li = ctx.li_samples(st, np.zeros(n, np.uint64), rays=rays[:n])
+    oli = o.li_rays(rays[:n], st, np.zeros(n, np.uint64))
+    err = np.abs(li - oli).max(1) / np.maximum(np.abs(oli).max(1), 1e-3)
+    assert (err < 1e-3).mean() > 0.95, (err < 1e-3).mean()
+    assert np.abs(li.mean(0) - oli.mean(0)).max() < 0.02 * oli.mean()
+    ctx.clear_film(); ctx.render(0, spp)
+    img = ctx.read_bitmap()
+    o.render(0, spp, mode=1, threads=8)
+    oimg = o.bitmap()
+    rel = np.abs(img.mean((0, 1)) - oimg.mean((0, 1))) / oimg.mean((0, 1))
+    assert rel.max() < 2e-3, rel
+
+
+def test_subsurface_render_against_oracle(loaded):
+    """cbox_subsurface.xml: image against the oracle at matched streams (the oracle's Li on this scene is bit-identical to
+    the reference's, tests/test_oracle.py), and the probe rays counted as closest-hit rays"""
+    W, H, spp = 64, 48, 16
+    hs, ctx = loaded("cbox_subsurface", W, H)
+    ctx.clear_film(); ctx.reset_stats(); ctx.render(0, spp)
+    img, film = ctx.read_bitmap(), ctx.read_film()
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML["cbox_subsurface"]), W, H, spp)
+    _, ost = o.render(0, spp, mode=1, threads=8)
+    oimg, ofilm = o.bitmap(), o.film()
+    assert np.array_equal(film[:, :, 3], ofilm[:, :, 3])
+    rel = np.abs(img.mean((0, 1)) - oimg.mean((0, 1))) / oimg.mean((0, 1))
+    assert rel.max() < 2e-3, rel
+    st = ctx.stats()
+    assert abs(st["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"]
+    assert abs(st["shadow_rays"] - ost["shadow"]) < 0.01 * ost["shadow"]
 
 
 def test_filter_pass_matches_oracle(loaded):

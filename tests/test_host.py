@@ -11,7 +11,8 @@ import nori_hip as NH
 import oracle_lib as O
 from conftest import ROOT, SCENES
 
-XMLS = ["cbox/cbox_path_mis.xml", "cbox/cbox_mirror_microfacet.xml", "table/table_path_mis.xml", "table/table_path_mis_microfacet.xml", "proj/dragon-diffuse.xml"]
+XMLS = ["cbox/cbox_path_mis.xml", "cbox/cbox_mirror_microfacet.xml", "table/table_path_mis.xml", "table/table_path_mis_microfacet.xml", "proj/dragon-diffuse.xml",
+        "proj/cbox_subsurface.xml", "proj/textureAndBump.xml", "proj/normal.xml"]
 
 
 def test_c_abi_exports_every_declared_symbol():
@@ -40,6 +41,9 @@ def test_host_loader_and_bvh_equal_the_oracle(xml):
     assert np.array_equal(idx, oidx)                                                       # leaf order bit-exact
     for s in range(hi["shapes"]):
         a, b = hs.mesh(s), o.shape(s)
+        if a is None:                                  # analytic sphere
+            assert b["type"] == 1
+            continue
         for k in ("V", "F", "cdf"):
             assert np.array_equal(a[k], b[k])
         for k in ("N", "UV"):
@@ -75,6 +79,56 @@ def test_flattened_tables_are_consistent():
     assert np.array_equal(nodes["lmin"], n32["bmin"][inner_idx + 1]) and np.array_equal(nodes["lmax"], n32["bmax"][inner_idx + 1])
     assert np.array_equal(nodes["rmin"], n32["bmin"][inner["w1"]]) and np.array_equal(nodes["rmax"], n32["bmax"][inner["w1"]])
     assert np.array_equal(prims["a"], shade["p0"]) and np.array_equal(prims["e1"], shade["p1"] - shade["p0"])
+
+
+@pytest.mark.parametrize("xml", ["proj/textureAndBump.xml", "proj/normal.xml", "proj/cbox_subsurface.xml"])
+def test_images_and_subsurface_parameters_flatten_like_the_oracle(xml):
+    """image tables (kind, size, uv transform, texels incl. the Sobel gradients of bump maps) and the per-shape
+    texture / modifier / subsurface fields: host plugins vs the oracle's independent restatement"""
+    path = os.path.join(SCENES, xml)
+    hs, o = NH.HostScene(path, 64, 48, 1), O.OracleScene(path, 64, 48, 1)
+    T = hs.tables()
+    ims = o.images()
+    # the host stores one table entry per plugin object, in shape order, albedo before modifier; map through the shapes
+    assert len(T["textures"]) == len(ims)
+    for s in range(hs.info()["shapes"]):
+        osh, hsh = o.shape_images(s), T["shapes"][s]
+        for field, k in (("albedo_tex", osh["albedo_tex"]), ("normal_tex", osh["normal_tex"])):
+            assert (hsh[field] == 0) == (k < 0)
+            if k < 0:
+                continue
+            t, m = T["textures"][hsh[field] - 1], ims[k]
+            assert (t["kind"], t["lookup"], t["width"], t["height"]) == (m["kind"], m["lookup"], m["cols"], m["rows"])
+            assert np.array_equal(t["scale"], m["scale"]) and np.array_equal(t["delta"], m["delta"])
+            assert np.array_equal(T["tex_data"][int(t["offset"]):int(t["offset"]) + 4 * m["cols"] * m["rows"]], m["texels"])
+        if hsh["bsdf"] == 4:
+            assert hsh["ss_cs"] == np.sqrt(np.float32(3)) and hsh["ss_cd"] == np.sqrt((osh["dmfp"] ** 2).sum(dtype=np.float32))
+            assert abs(hsh["int_ior"] - 1.3046) < 1e-6
+    if "subsurface" in xml:
+        assert sorted(T["shapes"]["bsdf"].tolist()).count(4) == 2 and len(ims) == 0
+
+
+def test_texture_plugins_report_errors_like_the_reference(tmp_path):
+    base = '<scene><integrator type="path_mis"/><camera type="perspective"/><mesh type="sphere">%s<emitter type="area"><color name="radiance" value="1 1 1"/></emitter></mesh></scene>'
+    def load(body):
+        p = tmp_path / "s.xml"
+        p.write_text(base % body)
+        return NH.HostScene(str(p))
+    with pytest.raises(NH.NoriHipError, match="could not be found"):
+        load('<bsdf type="diffuse"><texture type="image_color" name="albedo"><string name="filename" value="nope.jpg"/></texture></bsdf>')
+    with pytest.raises(NH.NoriHipError, match="does not match any field"):
+        load('<bsdf type="diffuse"><texture type="constant_color" name="kd"><color name="value" value="1 1 1"/></texture></bsdf>')
+    with pytest.raises(NH.NoriHipError, match="already an albedo"):
+        load('<bsdf type="subsurface"><color name="albedo" value="1 1 1"/><texture type="constant_color" name="albedo"/></bsdf>')
+    (tmp_path / "g.pgm").write_bytes(b"P5\n2 2\n255\n" + bytes([0, 64, 128, 255]))
+    mod = '<normalModifier type="bump_map"><string name="filename" value="g.pgm"/></normalModifier>'
+    with pytest.raises(NH.NoriHipError, match="multiple Normal modifier"):
+        load(mod + mod)
+    with pytest.raises(NH.NoriHipError, match="not of size 2 or 3"):
+        load('<normalModifier type="bump_map"><string name="filename" value="g.pgm"/><vector name="scale" value="1"/></normalModifier>')
+    hs = load(mod.replace("</normalModifier>", '<vector name="scale" value="2,4"/><point name="delta" value="0.5,0.25"/></normalModifier>'))
+    t = hs.tables()["textures"][0]
+    assert (t["kind"], t["width"], t["height"]) == (1, 2, 2) and t["scale"].tolist() == [2.0, 4.0] and t["delta"].tolist() == [0.5, 0.25]
 
 
 def test_single_leaf_scene_and_test_files_load():

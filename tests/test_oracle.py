@@ -15,6 +15,7 @@ SCENE_XML = {
     "table": "table/table_path_mis.xml",
     "table_microfacet": "table/table_path_mis_microfacet.xml",
     "dragon": "proj/dragon-diffuse.xml",
+    "cbox_subsurface": "proj/cbox_subsurface.xml",       # subsurface shapes: probe rays with the shape mask (src/subsurface.cpp)
 }
 
 
@@ -70,11 +71,88 @@ def test_oracle_li_on_reference_test_scenes():
 def test_oracle_bsdfs_bit_exact():
     g = np.load(os.path.join(GOLDEN, "bsdf.npz"))
     for k in g.files:
-        if k.endswith("_type") or k.endswith("_params") or k in ("wi", "sample"):
+        if k.endswith("_type") or k.endswith("_params") or k in ("wi", "sample") or k.startswith("ss_"):
             continue
         out = O.bsdf_sample(int(g[k + "_type"]), g[k + "_params"], g["wi"], g["sample"])
         ref = g[k]
         assert np.array_equal(out, ref, equal_nan=True), k
+
+
+def test_oracle_subsurface_probe_sampling_bit_exact():
+    # Subsurface::sampleDx (src/subsurface.cpp:199-249) through the reference's own class: probe origin, direction,
+    # mint, maxt and the disk sample, for three mean free paths
+    g = np.load(os.path.join(GOLDEN, "bsdf.npz"))
+    n = len(g["ss_p"])
+    for tag in ("ss_dx_0p1", "ss_dx_0p01", "ss_dx_4"):
+        out = O.ss_sample_dx(g[tag + "_dmfp"], g["ss_p"], g["ss_n"], np.arange(n), np.zeros(n))
+        assert np.array_equal(out, g[tag]), tag
+
+
+def _write_tiny_textured_scene(d, lookup):
+    """a quad with uv coordinates and a 3x2 colour image (values chosen so that every texel differs)"""
+    img = np.array([[[0, 10, 20], [50, 60, 70], [100, 110, 120]], [[150, 160, 170], [200, 210, 220], [250, 240, 230]]], np.uint8)
+    with open(os.path.join(d, "t.ppm"), "wb") as f:
+        f.write(b"P6\n# comment\n3 2\n255\n" + img.tobytes())
+    with open(os.path.join(d, "g.pgm"), "wb") as f:
+        f.write(b"P5\n3 2\n255\n" + img[:, :, 0].tobytes())
+    with open(os.path.join(d, "q.obj"), "w") as f:
+        f.write("v -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n")
+    xml = '''<scene><integrator type="path_mis"/>
+<camera type="perspective"><transform name="toWorld"><lookat origin="0,0,4" target="0,0,0" up="0,1,0"/></transform>
+<integer name="width" value="8"/><integer name="height" value="8"/></camera>
+<mesh type="obj"><string name="filename" value="q.obj"/>
+ <normalModifier type="bump_map"><string name="filename" value="g.pgm"/><float name="height" value="50"/><string name="lookup" value="%s"/></normalModifier>
+ <bsdf type="diffuse"><texture type="image_color" name="albedo"><string name="filename" value="t.ppm"/>
+  <vector name="scale" value="0.5,2"/><point name="delta" value="0.25,0.125"/><string name="lookup" value="%s"/></texture></bsdf>
+ <emitter type="area"><color name="radiance" value="1 1 1"/></emitter></mesh></scene>''' % (lookup, lookup)
+    path = os.path.join(d, "scene_%s.xml" % lookup)
+    with open(path, "w") as f:
+        f.write(xml)
+    return path, img
+
+
+def test_oracle_image_lookups_on_a_known_image(tmp_path):
+    # image order: the normal modifier is registered before the bsdf's texture (XML order)
+    rng = np.random.default_rng(11)
+    uv = rng.random((500, 2)).astype(np.float32) * 3 - 1
+    path, img = _write_tiny_textured_scene(str(tmp_path), "nearest")
+    o = O.OracleScene(path)
+    ims = o.images()
+    assert [(m["kind"], m["cols"], m["rows"], m["lookup"]) for m in ims] == [(1, 3, 2, 0), (0, 3, 2, 0)]
+    assert np.array_equal(ims[1]["texels"].reshape(2, 3, 4)[:, :, :3], img) and np.all(ims[1]["texels"].reshape(2, 3, 4)[:, :, 3] == 255)
+    # cv::Sobel 3x3, reflect-101 border, scale 50, written out by hand for the 2-row image (row -1 = row 1, col -1 = col 1)
+    g = img[:, :, 0].astype(np.int64)
+    pad = np.pad(g, 1, mode="reflect")
+    gx = np.zeros((2, 3), np.int64)
+    gy = np.zeros((2, 3), np.int64)
+    for r in range(2):
+        for c in range(3):
+            w = pad[r:r + 3, c:c + 3]
+            gx[r, c] = (w[0, 2] + 2 * w[1, 2] + w[2, 2]) - (w[0, 0] + 2 * w[1, 0] + w[2, 0])
+            gy[r, c] = (w[2, 0] + 2 * w[2, 1] + w[2, 2]) - (w[0, 0] + 2 * w[0, 1] + w[0, 2])
+    sob = np.frombuffer(ims[0]["texels"].tobytes(), np.int16).reshape(2, 3, 2)
+    assert np.array_equal(sob[:, :, 0], np.clip(gx * 50, -32768, 32767)) and np.array_equal(sob[:, :, 1], np.clip(gy * 50, -32768, 32767))
+    # nearest colour lookup = the CPU renderer's (src/imagetexture.cpp:49-77): x, y rescaled, row = x*rows, col = y*cols, value / 255
+    x = uv[:, 0] / np.float32(0.5) - np.float32(0.25)
+    y = uv[:, 1] / np.float32(2) - np.float32(0.125)
+    x, y = x - np.floor(x), y - np.floor(y)
+    row, col = np.minimum((x * 2).astype(int), 1), np.minimum((y * 3).astype(int), 2)
+    assert np.array_equal(o.image_eval(1, uv), (img[row, col].astype(np.float32) / np.float32(255)))
+    # bilinear = CUDA's tex2D(tex, y, x): texel centres at +0.5, wrap, 8-bit weights; then sRGB -> linear
+    path, _ = _write_tiny_textured_scene(str(tmp_path), "bilinear")
+    o2 = O.OracleScene(path)
+    xb, yb = y.astype(np.float64) * 3 - 0.5, x.astype(np.float64) * 2 - 0.5
+    i0, j0 = np.floor(xb).astype(int), np.floor(yb).astype(int)
+    a, b = np.floor((xb - i0) * 256 + 0.5) / 256, np.floor((yb - j0) * 256 + 0.5) / 256
+    t = img.astype(np.float64) / 255
+    v = ((1 - a) * (1 - b))[:, None] * t[j0 % 2, i0 % 3] + (a * (1 - b))[:, None] * t[j0 % 2, (i0 + 1) % 3] + \
+        ((1 - a) * b)[:, None] * t[(j0 + 1) % 2, i0 % 3] + (a * b)[:, None] * t[(j0 + 1) % 2, (i0 + 1) % 3]
+    lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4)
+    assert np.abs(o2.image_eval(1, uv) - lin).max() < 2e-4            # float vs double, and weights that fall on a rounding boundary
+    # bump: unit normals, equal to the frame normal where both gradients vanish
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (len(uv), 1))
+    nb = o2.image_eval(0, uv, nrm)
+    assert np.allclose(np.linalg.norm(nb, axis=1), 1, atol=1e-5)
 
 
 def test_oracle_passes_the_references_own_ttests():
