@@ -189,6 +189,7 @@ void flattenScene(const Scene *scene, FlatScene &out) {
         for (size_t k = 0; k < seen.size(); ++k) if (seen[k] == img) return (uint32_t) k + 1;
         NoriHipTexture t = img->meta; t.offset = out.tex_data.size();
         out.tex_data.insert(out.tex_data.end(), img->texels.begin(), img->texels.end());
+        if (out.textures.size() >= 65535) throw NoriException("flattenScene: too many images (16-bit image index)");
         out.textures.push_back(t); seen.push_back(img);
         return (uint32_t) out.textures.size();
     };
@@ -199,8 +200,8 @@ void flattenScene(const Scene *scene, FlatScene &out) {
         d.alpha = 0.1f; d.int_ior = 1.5046f; d.ext_ior = 1.000277f; d.ks = 0.5f;
         sh->getBSDF()->describe(d);
         d.emitter = -1;
-        d.albedo_tex = addImage(sh->getBSDF()->albedoImage());
-        d.normal_tex = addImage(sh->getNormalModifier() ? sh->getNormalModifier()->image() : nullptr);
+        d.albedo_tex = (uint16_t) addImage(sh->getBSDF()->albedoImage());
+        d.normal_tex = (uint16_t) addImage(sh->getNormalModifier() ? sh->getNormalModifier()->image() : nullptr);
         if (sh->isSphere()) { const Sphere *sp = static_cast<const Sphere *>(sh); Point3f c = sp->getCenter(); d.center[0] = c.x; d.center[1] = c.y; d.center[2] = c.z; d.radius = sp->getRadius(); }
         else { const Mesh *m = static_cast<const Mesh *>(sh); d.flags = (m->getVertexNormals().empty() ? 0u : 1u) | (m->getVertexTexCoords().empty() ? 0u : 2u); }
     }

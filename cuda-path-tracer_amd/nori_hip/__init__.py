@@ -42,15 +42,15 @@ PRIM_DTYPE = np.dtype([("a", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("pr
 SHADE_DTYPE = np.dtype([("p0", "<f4", 3), ("p1", "<f4", 3), ("p2", "<f4", 3), ("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3),
                         ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("uv2", "<f4", 2)])
 SHAPE_DTYPE = np.dtype([("type", "<i4"), ("bsdf", "<i4"), ("emitter", "<i4"), ("flags", "<u4"), ("albedo", "<f4", 3), ("alpha", "<f4"),
-                        ("int_ior", "<f4"), ("ext_ior", "<f4"), ("ks", "<f4"), ("center", "<f4", 3), ("radius", "<f4"), ("albedo_tex", "<u4"),
-                        ("normal_tex", "<u4"), ("ss_cs", "<f4"), ("ss_cd", "<f4"), ("pad", "<u4")])
+                        ("int_ior", "<f4"), ("ext_ior", "<f4"), ("ks", "<f4"), ("center", "<f4", 3), ("radius", "<f4"), ("albedo_tex", "<u2"),
+                        ("normal_tex", "<u2")])         # subsurface shapes: alpha holds ss_cs, ks holds ss_cd (unions in nori_hip.h)
 TEXTURE_DTYPE = np.dtype([("kind", "<u4"), ("lookup", "<u4"), ("width", "<u4"), ("height", "<u4"), ("offset", "<u8"), ("scale", "<f4", 2), ("delta", "<f4", 2)])
 EMITTER_DTYPE = np.dtype([("radiance", "<f4", 3), ("shape", "<i4"), ("cdf_offset", "<u4"), ("n_tris", "<u4"), ("light_prim_offset", "<u4"),
                           ("area_pdf", "<f4")])
 NODE32_DTYPE = np.dtype([("w0", "<u4"), ("w1", "<u4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3)])
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("mint", "<f4"), ("d", "<f4", 3), ("maxt", "<f4")])
 HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
-assert NODE_DTYPE.itemsize == 64 and PRIM_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 96 and SHAPE_DTYPE.itemsize == 80 and EMITTER_DTYPE.itemsize == 32 and TEXTURE_DTYPE.itemsize == 40
+assert NODE_DTYPE.itemsize == 64 and PRIM_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 96 and SHAPE_DTYPE.itemsize == 64 and EMITTER_DTYPE.itemsize == 32 and TEXTURE_DTYPE.itemsize == 40
 
 MISS = 0xFFFFFFFF
 _hip = None

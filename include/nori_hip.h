@@ -75,18 +75,21 @@ typedef struct NoriHipShadePrim {
     float uv0[2], uv1[2], uv2[2];
 } NoriHipShadePrim;
 
+/* 64 bytes: one cache line per shape */
 typedef struct NoriHipShape {
     int32_t  type;                 /* NORI_HIP_SHAPE_* */
     int32_t  bsdf;                 /* NORI_HIP_BSDF_* */
     int32_t  emitter;              /* index into emitters, -1 if none */
     uint32_t flags;                /* bit0 has vertex normals, bit1 has uvs */
-    float    albedo[3];            /* diffuse albedo | microfacet kd */
-    float    alpha, int_ior, ext_ior, ks;
+    float    albedo[3];            /* diffuse / subsurface albedo | microfacet kd (constant colour) */
+    union { float alpha;           /* microfacet */
+            float ss_cs; };        /* subsurface: colorNorm(s) (src/subsurface.cpp:91-97) */
+    float    int_ior, ext_ior;
+    union { float ks;              /* microfacet: 1 - max(kd) */
+            float ss_cd; };        /* subsurface: colorNorm(dmfp) (src/subsurface.cpp:108-119) */
     float    center[3], radius;    /* sphere */
-    uint32_t albedo_tex;           /* 0: `albedo` is the constant colour; k: textures[k-1] (NORI_HIP_TEX_COLOR) gives it */
-    uint32_t normal_tex;           /* 0: none; k: textures[k-1] (NORI_HIP_TEX_BUMP / _NORMAL) replaces the shading normal */
-    float    ss_cs, ss_cd;         /* subsurface: colorNorm(s), colorNorm(dmfp) (src/subsurface.cpp:94-97,108-119) */
-    uint32_t pad;
+    uint16_t albedo_tex;           /* 0: `albedo` is the colour; k: textures[k-1] (NORI_HIP_TEX_COLOR) gives it at the hit's uv */
+    uint16_t normal_tex;           /* 0: none; k: textures[k-1] (NORI_HIP_TEX_BUMP / _NORMAL) replaces the shading normal */
 } NoriHipShape;
 
 /*

@@ -102,7 +102,7 @@ def test_images_and_subsurface_parameters_flatten_like_the_oracle(xml):
             assert np.array_equal(t["scale"], m["scale"]) and np.array_equal(t["delta"], m["delta"])
             assert np.array_equal(T["tex_data"][int(t["offset"]):int(t["offset"]) + 4 * m["cols"] * m["rows"]], m["texels"])
         if hsh["bsdf"] == 4:
-            assert hsh["ss_cs"] == np.sqrt(np.float32(3)) and hsh["ss_cd"] == np.sqrt((osh["dmfp"] ** 2).sum(dtype=np.float32))
+            assert hsh["alpha"] == np.sqrt(np.float32(3)) and hsh["ks"] == np.sqrt((osh["dmfp"] ** 2).sum(dtype=np.float32))   # ss_cs, ss_cd
             assert abs(hsh["int_ior"] - 1.3046) < 1e-6
     if "subsurface" in xml:
         assert sorted(T["shapes"]["bsdf"].tolist()).count(4) == 2 and len(ims) == 0
