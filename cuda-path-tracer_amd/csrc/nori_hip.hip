@@ -211,7 +211,7 @@ ND_RENDER_KERNEL(5)
 ND_RENDER_KERNEL(6)
 ND_RENDER_KERNEL(8)
 // scenes with images or subsurface shapes (DevScene::textures / NORI_HIP_BSDF_SUBSURFACE): one register budget
-__global__ __launch_bounds__(MEGA_THREADS) void k_render_ext(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
+__global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_ext(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     render_body<true>(sc, job, film, work_counter, stats, n_cached); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -784,6 +784,8 @@ struct NoriHipContext {
     std::vector<hipEvent_t> ext_ev;   // pairs of events around the extend launches since the last reset_stats
     size_t ext_used = 0; double ext_ms_acc = 0.0; uint64_t ext_launches = 0;
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
+    bool pipeline_forced = false;     // NORI_HIP_PIPELINE was given; otherwise EXT scenes take the single kernel (measured faster: the
+                                      // probe rays and image lookups of their shading are per-lane work the stages cannot batch)
     unsigned int finish_below = 0;    // live paths below which k_finish takes over; 0 = a quarter of the pool (NORI_HIP_FINISH)
     int shade_waves = 4;              // k_shade variant: waves per SIMD (NORI_HIP_SHADE_WAVES = 3, 4, 5, 6 or 8)
     int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
@@ -839,7 +841,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipMalloc((void **) &c->d_stats, ND_STRIPES * sizeof(DevStats)));
     HIPCHK(hipMemset(c->d_stats, 0, ND_STRIPES * sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
-    if (const char *e = getenv("NORI_HIP_PIPELINE")) c->pipeline = (std::string(e) == "mega") ? 0 : 1;
+    if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
@@ -1061,7 +1063,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     RenderJob job; job.x0 = x0; job.y0 = y0; job.tw = x1 - x0; job.th = y1 - y0; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin;
     job.total = (unsigned long long) job.tw * job.th * job.nspp;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
-    if (ctx->pipeline == 0) {
+    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced)) {
         // single persistent kernel with per-lane path regeneration
         unsigned long long chunks = (job.total + MEGA_THREADS - 1) / MEGA_THREADS;
         const int W = ctx->mega_waves;
