@@ -148,6 +148,7 @@ def main():
     T = hs.tables()
     info_ext = len(T["textures"]) > 0 or bool((T["shapes"]["bsdf"] == 4).any())      # images or subsurface shapes: the EXT kernels run
     ctx = hs.preprocess(device=local)
+    bi = ctx.build_info()
     film = film_tensor(ctx, torch) if world > 1 else None
     spp = w["spp"]
     samples_per_step = w["width"] * w["height"] * spp
@@ -223,7 +224,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if w["xml"] is None else "reference scene files (scenes/)",
         "config": {"workload": w["name"], "width": w["width"], "height": w["height"], "spp_per_gpu": spp, "triangles": info["prims"],
                    "bvh_nodes_64B": info["wide_nodes"], "partition": "spp slices, RCCL all-reduce of the fp32 film" if world > 1 else "single GPU",
-                   "scene_load_s": round(load_s, 2), "bvh_build_s": round(hs.bvh_build_seconds(), 3)},
+                   "scene_load_s": round(load_s, 2), "bvh_build_s": round(hs.bvh_build_seconds(), 3),
+                   "bvh": ("device LBVH, %.1f ms, %d of %d nodes used, depth %d" % (bi["build_ms"], bi["n_used"], bi["n_nodes"], bi["depth"])) if bi["n_nodes"] or bi["build_ms"] else "host SAH (reference order)"},
         "mrays_per_s": round(rays * world * args.steps / dt / 1e6, 2),
         "rays_per_sample": round(rays / samples_per_step, 3),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

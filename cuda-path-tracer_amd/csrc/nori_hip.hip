@@ -13,6 +13,7 @@
 //   k_bitmap       ImageBlock::toBitmap (src/block.cpp:76-82)
 //   k_srgb, k_nlmeans   the filter pass of the CUDA fork (cuda/filter.cc.cu:33-110)
 #include <hip/hip_runtime.h>
+#include "nori_lbvh.h"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -771,6 +772,8 @@ struct NoriHipContext {
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
     NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
+    lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
+    uint32_t lbvh_leaf = 4;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF)
     float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
     unsigned long long *d_counter = nullptr; DevStats *d_stats = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -842,6 +845,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipMemset(c->d_stats, 0, ND_STRIPES * sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
+    if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
@@ -881,12 +885,12 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     return NORI_HIP_OK;
 }
 
-int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
+static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, const bool device_build) {
     CTXCHK(ctx);
     if (!d) return fail(NORI_HIP_EINVAL, "scene description is null");
     if (d->n_prims == 0 || !d->prims || !d->shade_prims) return fail(NORI_HIP_EINVAL, "scene has no primitives");
     if (d->n_shapes == 0 || !d->shapes) return fail(NORI_HIP_EINVAL, "scene has no shapes");
-    if (d->n_nodes > 0 && !d->nodes) return fail(NORI_HIP_EINVAL, "nodes is null");
+    if (!device_build && d->n_nodes > 0 && !d->nodes) return fail(NORI_HIP_EINVAL, "nodes is null");
     if (d->camera.width <= 0 || d->camera.height <= 0) return fail(NORI_HIP_EINVAL, "bad camera size");
     // validate every index the kernels will follow: a bad table must be rejected here, not fault on the GPU
     auto ref_ok = [&](uint32_t r) {
@@ -894,11 +898,13 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
         if (r & NORI_HIP_LEAF_BIT) return (r & 0x7fffffffu) < d->n_prims;
         return r < d->n_nodes;
     };
-    if (d->root == NORI_HIP_NO_CHILD || !ref_ok(d->root)) return fail(NORI_HIP_EINVAL, "bad root reference");
-    for (uint32_t i = 0; i < d->n_nodes; ++i)
-        if (!ref_ok(d->nodes[i].left) || d->nodes[i].left == NORI_HIP_NO_CHILD || !ref_ok(d->nodes[i].right))
-            return fail(NORI_HIP_EINVAL, "node " + std::to_string(i) + " has a child reference out of range");
-    if (!(d->prims[d->n_prims - 1].shape_flags & 0x80000000u)) return fail(NORI_HIP_EINVAL, "last primitive record does not end a leaf");
+    if (!device_build) {
+        if (d->root == NORI_HIP_NO_CHILD || !ref_ok(d->root)) return fail(NORI_HIP_EINVAL, "bad root reference");
+        for (uint32_t i = 0; i < d->n_nodes; ++i)
+            if (!ref_ok(d->nodes[i].left) || d->nodes[i].left == NORI_HIP_NO_CHILD || !ref_ok(d->nodes[i].right))
+                return fail(NORI_HIP_EINVAL, "node " + std::to_string(i) + " has a child reference out of range");
+        if (!(d->prims[d->n_prims - 1].shape_flags & 0x80000000u)) return fail(NORI_HIP_EINVAL, "last primitive record does not end a leaf");
+    }
     for (uint32_t i = 0; i < d->n_prims; ++i)
         if ((d->prims[i].shape_flags & 0xffffffu) >= d->n_shapes) return fail(NORI_HIP_EINVAL, "primitive record " + std::to_string(i) + " names a shape out of range");
     bool ext = false;
@@ -935,7 +941,24 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     // of the node array in LDS and test `index < cached`.  Only the numbering changes; boxes, child order and the
     // leaf records are the caller's.
     uint32_t root = d->root, n_top = 0;
-    {
+    float root_min[3] = {d->root_min[0], d->root_min[1], d->root_min[2]}, root_max[3] = {d->root_max[0], d->root_max[1], d->root_max[2]};
+    ctx->lbvh = lbvh::Result();
+    if (device_build) {
+        // the tree is built here, on the device, from the records in whatever order they came
+        NoriHipPrim *tmp_prims = nullptr; NoriHipShadePrim *tmp_shade = nullptr;
+        if ((rc = upload(tmp_prims, d->prims, d->n_prims))) return rc;
+        if ((rc = upload(tmp_shade, d->shade_prims, d->n_prims))) { hipFree(tmp_prims); return rc; }
+        hipError_t e1_ = hipMalloc((void **) &ctx->d_prims, (size_t) d->n_prims * sizeof(NoriHipPrim));
+        hipError_t e2_ = hipMalloc((void **) &ctx->d_shade, (size_t) d->n_prims * sizeof(NoriHipShadePrim));
+        hipError_t e3_ = hipMalloc((void **) &ctx->d_nodes, (size_t) std::max<uint32_t>(d->n_prims - 1, 1u) * sizeof(NoriHipNode));
+        std::string lerr;
+        rc = (e1_ != hipSuccess || e2_ != hipSuccess || e3_ != hipSuccess) ? NORI_HIP_EDEVICE
+             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf, ND_STACK - 2, ctx->lbvh, lerr);
+        hipFree(tmp_prims); hipFree(tmp_shade);
+        if (rc) { ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
+        root = ctx->lbvh.root;
+        for (int i = 0; i < 3; ++i) { root_min[i] = ctx->lbvh.root_min[i]; root_max[i] = ctx->lbvh.root_max[i]; }
+    } else {
         std::vector<NoriHipNode> nodes(d->nodes, d->nodes + d->n_nodes);
         if (d->n_nodes > 0 && !(d->root & NORI_HIP_LEAF_BIT)) {
             const uint32_t top_max = std::min<uint32_t>(d->n_nodes, 2560u);      // 160 KB of LDS / 64 B
@@ -956,8 +979,10 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
         }
         if ((rc = upload(ctx->d_nodes, nodes.data(), d->n_nodes))) return rc;
     }
-    if ((rc = upload(ctx->d_prims, d->prims, d->n_prims))) return rc;
-    if ((rc = upload(ctx->d_shade, d->shade_prims, d->n_prims))) return rc;
+    if (!device_build) {
+        if ((rc = upload(ctx->d_prims, d->prims, d->n_prims))) return rc;
+        if ((rc = upload(ctx->d_shade, d->shade_prims, d->n_prims))) return rc;
+    }
     if ((rc = upload(ctx->d_light, d->light_prims, d->n_light_prims))) return rc;
     if ((rc = upload(ctx->d_shapes, d->shapes, d->n_shapes))) return rc;
     if ((rc = upload(ctx->d_emitters, d->emitters, d->n_emitters))) return rc;
@@ -969,8 +994,9 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
     sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
-    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = ctx->ordered ? 1 : 0;
-    for (int i = 0; i < 3; ++i) { sc.root_min[i] = d->root_min[i]; sc.root_max[i] = d->root_max[i]; }
+    // a device-built tree has no reference child order to keep: the nearer child is entered first
+    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = (ctx->ordered || device_build) ? 1 : 0;
+    for (int i = 0; i < 3; ++i) { sc.root_min[i] = root_min[i]; sc.root_max[i] = root_max[i]; }
     sc.cam = d->camera;
     sc.inv_w = 1.0f / (float) d->camera.width; sc.inv_h = 1.0f / (float) d->camera.height;
     ctx->border = (int) std::ceil(d->camera.filter_radius - 0.5f);
@@ -980,6 +1006,14 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) {
     HIPCHK(hipMalloc((void **) &ctx->d_film, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4)));
     HIPCHK(hipMemset(ctx->d_film, 0, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4)));
     ctx->have_scene = true;
+    return NORI_HIP_OK;
+}
+
+int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *d) { return upload_scene_impl(ctx, d, false); }
+int nori_hip_upload_scene_build(NoriHipContext *ctx, const NoriHipSceneDesc *d) { return upload_scene_impl(ctx, d, true); }
+int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used, uint32_t *depth, double *build_ms) {
+    SCENECHK(ctx);
+    if (n_nodes) *n_nodes = ctx->lbvh.n_nodes; if (n_used) *n_used = ctx->lbvh.n_used; if (depth) *depth = ctx->lbvh.depth; if (build_ms) *build_ms = ctx->lbvh.build_ms;
     return NORI_HIP_OK;
 }
 

@@ -1,0 +1,27 @@
+// Device-side BVH construction: a linear BVH over Morton-sorted primitive records, emitted in the
+// 64-byte two-box node layout of include/nori_hip.h.  NOT the reference's tree (src/bvh.cpp builds a SAH tree on the
+// host; cuda-path-tracer_amd/host/bvh.cpp reproduces that one and stays the parity mode): closest hits are the same
+// primitive except where two primitives tie in t, any-hit answers are identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/nori_hip.h"
+
+namespace lbvh {
+
+struct Result {
+    uint32_t root;                 // child reference of the root
+    uint32_t n_nodes;              // size of the node array (n_prims - 1; entries below collapsed leaves are unused)
+    uint32_t n_used, depth;        // inner nodes in use, depth of the tree (levels of inner nodes)
+    float root_min[3], root_max[3];
+    double build_ms;               // device time of the whole build (HIP events)
+};
+
+// prims_in / shade_in: n records in any order (bit 31 of shape_flags ignored).  prims_out / shade_out: n records in
+// leaf order; nodes_out: max(n - 1, 1) nodes.  All device pointers.  Leaves hold at most `leaf_max` records.
+// Returns 0 or a negative NORI_HIP_E* code with `err` set.
+int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, uint32_t max_depth, Result &res, std::string &err);
+
+} // namespace lbvh

@@ -1,0 +1,297 @@
+// Linear BVH construction on the GPU (see nori_lbvh.h).
+//
+//   k_boxes     per record: its box (the reference's per-primitive boxes, src/mesh.cpp:170-175, src/sphere.cpp:38) and
+//               the bounds of the box centres (block reduction, then six atomics per block)
+//   k_morton    63-bit Morton code of the box centre (21 bits per axis), value = record index
+//   hipcub      radix sort of (code, index)
+//   k_hierarchy one thread per inner node: its range of sorted records and split (Karras 2012, "Maximizing
+//               parallelism in the construction of BVHs, octrees and k-d trees"); equal codes are told apart by
+//               their position, so keys are unique
+//   k_refit     one thread per leaf walks to the root; the second thread to arrive at a node computes its box
+//   k_depth     depth of every leaf -> depth of the tree (the traversal stack holds ND_STACK entries)
+//   k_reorder   records into sorted (leaf) order
+//   k_emit      one thread per inner node: the 64-byte node with both children's boxes; subtrees of at most
+//               `leaf_max` records become one leaf (their records are contiguous in sorted order)
+#include "nori_lbvh.h"
+#include <hipcub/hipcub.hpp>
+#include <vector>
+#include <algorithm>
+
+namespace lbvh {
+namespace {
+
+#define LB_LEAF 0x80000000u
+
+// order-preserving map float -> uint32 (for atomicMin / atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t f2o(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ __forceinline__ float o2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    union { uint32_t u; float f; } c; c.u = u; return c.f;
+}
+
+__device__ __forceinline__ void record_box(const NoriHipPrim &p, const NoriHipShadePrim &s, float mn[3], float mx[3]) {
+    if (p.shape_flags & 0x40000000u) {                       // sphere: centre -+ radius (src/sphere.cpp:33-34)
+        for (int a = 0; a < 3; ++a) { mn[a] = p.a[a] - p.e1[0]; mx[a] = p.a[a] + p.e1[0]; }
+        return;
+    }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = fminf(fminf(s.p0[a], s.p1[a]), s.p2[a]);
+        mx[a] = fmaxf(fmaxf(s.p0[a], s.p1[a]), s.p2[a]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_boxes(uint32_t n, const NoriHipPrim *prims, const NoriHipShadePrim *shade, float4 *pmin, float4 *pmax, uint32_t *cbounds) {
+    __shared__ uint32_t red[6];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0xffffffffu; else if (threadIdx.x < 6) red[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float mn[3], mx[3]; record_box(prims[i], shade[i], mn, mx);
+        pmin[i] = make_float4(mn[0], mn[1], mn[2], 0.f); pmax[i] = make_float4(mx[0], mx[1], mx[2], 0.f);
+        for (int a = 0; a < 3; ++a) { float c = 0.5f * (mn[a] + mx[a]); atomicMin(&red[a], f2o(c)); atomicMax(&red[3 + a], f2o(c)); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&cbounds[threadIdx.x], red[threadIdx.x]); else if (threadIdx.x < 6) atomicMax(&cbounds[threadIdx.x], red[threadIdx.x]);
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {         // bit k -> bit 3k
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_morton(uint32_t n, const float4 *pmin, const float4 *pmax, const uint32_t *cbounds, unsigned long long *keys, uint32_t *vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = pmin[i], b = pmax[i];
+    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+    unsigned long long code = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float lo = o2f(cbounds[k]), hi = o2f(cbounds[3 + k]);
+        float t = (hi > lo) ? (c[k] - lo) / (hi - lo) : 0.f;
+        t = fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
+        code |= spread21((unsigned long long) t) << (2 - k);
+    }
+    keys[i] = code; vals[i] = i;
+}
+
+// length of the common prefix of the keys at sorted positions i and j; -1 outside the array
+__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long x = keys[i] ^ keys[j];
+    if (x == 0ull) return 64 + __clz((unsigned int) (i ^ j));
+    return __clzll((long long) x);
+}
+
+__global__ __launch_bounds__(256) void k_hierarchy(int n, const unsigned long long *keys, uint32_t *left, uint32_t *right, uint32_t *first, uint32_t *last,
+                                                   uint32_t *parent_inner, uint32_t *parent_leaf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1) if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t lref = (lo == gamma) ? (LB_LEAF | (uint32_t) gamma) : (uint32_t) gamma;
+    const uint32_t rref = (hi == gamma + 1) ? (LB_LEAF | (uint32_t) (gamma + 1)) : (uint32_t) (gamma + 1);
+    left[i] = lref; right[i] = rref; first[i] = (uint32_t) lo; last[i] = (uint32_t) hi;
+    if (lref & LB_LEAF) parent_leaf[gamma] = (uint32_t) i; else parent_inner[gamma] = (uint32_t) i;
+    if (rref & LB_LEAF) parent_leaf[gamma + 1] = (uint32_t) i; else parent_inner[gamma + 1] = (uint32_t) i;
+    if (i == 0) parent_inner[0] = 0xffffffffu;
+}
+
+// node boxes cross from the thread that wrote them to the thread that arrives second at the parent, possibly on
+// another XCD: device-scope atomic stores / loads, ordered by fences around the arrival counter
+__device__ __forceinline__ void st_dev(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_dev(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void k_refit(uint32_t n, const uint32_t *vals, const float4 *pmin, const float4 *pmax, const uint32_t *left, const uint32_t *right,
+                                               const uint32_t *parent_inner, const uint32_t *parent_leaf, float *nbox /* 8 floats per inner node: min xyz _, max xyz _ */,
+                                               uint32_t *arrived) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t cur = parent_leaf[i];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&arrived[cur], 1u) == 0u) return;                   // the sibling subtree is not finished: its thread goes on
+        __threadfence();
+        float mn[3], mx[3];
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t c = side ? right[cur] : left[cur];
+            float cmn[3], cmx[3];
+            if (c & LB_LEAF) {
+                const float4 a = pmin[vals[c & 0x7fffffffu]], b = pmax[vals[c & 0x7fffffffu]];
+                cmn[0] = a.x; cmn[1] = a.y; cmn[2] = a.z; cmx[0] = b.x; cmx[1] = b.y; cmx[2] = b.z;
+            } else {
+                const float *q = nbox + 8 * (size_t) c;
+                for (int a = 0; a < 3; ++a) { cmn[a] = ld_dev(q + a); cmx[a] = ld_dev(q + 4 + a); }
+            }
+            for (int a = 0; a < 3; ++a) { mn[a] = side ? fminf(mn[a], cmn[a]) : cmn[a]; mx[a] = side ? fmaxf(mx[a], cmx[a]) : cmx[a]; }
+        }
+        float *q = nbox + 8 * (size_t) cur;
+        for (int a = 0; a < 3; ++a) { st_dev(q + a, mn[a]); st_dev(q + 4 + a, mx[a]); }
+        if (cur == 0u) return;
+        cur = parent_inner[cur];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_depth(uint32_t n, const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t *max_depth) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t d = 0;
+    if (i < n) { d = 1; for (uint32_t cur = parent_leaf[i]; cur != 0u; cur = parent_inner[cur]) ++d; }
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_down(d, off, 64); d = o > d ? o : d; }
+    if ((threadIdx.x & 63u) == 0u) atomicMax(max_depth, d);
+}
+
+__global__ __launch_bounds__(256) void k_reorder(uint32_t n, const uint32_t *vals, const NoriHipPrim *pin, const NoriHipShadePrim *sin, NoriHipPrim *pout, NoriHipShadePrim *sout) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = vals[i];
+    NoriHipPrim p = pin[src]; p.shape_flags &= 0x7fffffffu;
+    pout[i] = p; sout[i] = sin[src];
+}
+
+__global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t leaf_max, const uint32_t *vals, const float4 *pmin, const float4 *pmax, const uint32_t *left,
+                                              const uint32_t *right, const uint32_t *first, const uint32_t *last, const float *nbox, NoriHipNode *nodes,
+                                              NoriHipPrim *pout, uint32_t *n_used) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    NoriHipNode w;
+    if (i != 0u && last[i] - first[i] + 1u <= leaf_max) {                 // inside a collapsed subtree: never referenced
+        for (int a = 0; a < 3; ++a) { w.lmin[a] = w.lmax[a] = w.rmin[a] = w.rmax[a] = 0.f; }
+        w.left = w.right = NORI_HIP_NO_CHILD; w.lcount = w.rcount = 0;
+        nodes[i] = w;
+        return;
+    }
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t c = side ? right[i] : left[i];
+        float *mn = side ? w.rmin : w.lmin, *mx = side ? w.rmax : w.lmax;
+        uint32_t ref, count;
+        if (c & LB_LEAF) {
+            const uint32_t pos = c & 0x7fffffffu;
+            const float4 a = pmin[vals[pos]], b = pmax[vals[pos]];
+            mn[0] = a.x; mn[1] = a.y; mn[2] = a.z; mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
+            ref = LB_LEAF | pos; count = 1;
+            atomicOr(&pout[pos].shape_flags, 0x80000000u);
+        } else {
+            const float *q = nbox + 8 * (size_t) c;
+            for (int a = 0; a < 3; ++a) { mn[a] = q[a]; mx[a] = q[4 + a]; }
+            const uint32_t sz = last[c] - first[c] + 1u;
+            if (sz <= leaf_max) { ref = LB_LEAF | first[c]; count = sz; atomicOr(&pout[last[c]].shape_flags, 0x80000000u); }
+            else { ref = c; count = 0; }
+        }
+        if (side) { w.right = ref; w.rcount = count; } else { w.left = ref; w.lcount = count; }
+    }
+    nodes[i] = w;
+    atomicAdd(n_used, 1u);
+}
+
+__global__ void k_mark_last(NoriHipPrim *pout, uint32_t pos) { pout[pos].shape_flags |= 0x80000000u; }
+
+} // namespace
+
+int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, uint32_t max_depth, Result &res, std::string &err) {
+    std::vector<void *> owned; hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() { for (void *p : owned) (void) hipFree(p); owned.clear(); if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); e0 = e1 = nullptr; };
+#define LCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); cleanup(); return NORI_HIP_EDEVICE; } } while (0)
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) owned.push_back(*p); return e; };
+    if (n == 0 || leaf_max == 0) { err = "lbvh: nothing to build"; return NORI_HIP_EINVAL; }
+    if (n >= 0x7fffffffu) { err = "lbvh: too many records"; return NORI_HIP_EINVAL; }
+    const unsigned blocks = (n + 255u) / 256u;
+    LCHK(hipEventCreate(&e0)); LCHK(hipEventCreate(&e1));
+    float4 *pmin, *pmax; uint32_t *cb;
+    LCHK(alloc((void **) &pmin, (size_t) n * 16)); LCHK(alloc((void **) &pmax, (size_t) n * 16)); LCHK(alloc((void **) &cb, 8 * 4));
+    const uint32_t cb_init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};     // [6] = tree depth, [7] = nodes in use
+    LCHK(hipMemcpyAsync(cb, cb_init, sizeof(cb_init), hipMemcpyHostToDevice, stream));
+    LCHK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(k_boxes, dim3(blocks), dim3(256), 0, stream, n, prims_in, shade_in, pmin, pmax, cb);
+    LCHK(hipGetLastError());
+    res = Result();
+    if (n <= leaf_max) {
+        // one leaf: the root is a leaf reference, no inner node (include/nori_hip.h: NoriHipSceneDesc::root)
+        std::vector<uint32_t> ident(n); for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+        uint32_t *vals; LCHK(alloc((void **) &vals, (size_t) n * 4));
+        LCHK(hipMemcpyAsync(vals, ident.data(), (size_t) n * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals, prims_in, shade_in, prims_out, shade_out);
+        hipLaunchKernelGGL(k_mark_last, dim3(1), dim3(1), 0, stream, prims_out, n - 1);
+        LCHK(hipGetLastError());
+        std::vector<float4> hmn(n), hmx(n);
+        LCHK(hipMemcpyAsync(hmn.data(), pmin, (size_t) n * 16, hipMemcpyDeviceToHost, stream));
+        LCHK(hipMemcpyAsync(hmx.data(), pmax, (size_t) n * 16, hipMemcpyDeviceToHost, stream));
+        LCHK(hipEventRecord(e1, stream));
+        LCHK(hipStreamSynchronize(stream));
+        for (int a = 0; a < 3; ++a) { res.root_min[a] = 3.402823466e38f; res.root_max[a] = -3.402823466e38f; }
+        for (uint32_t i = 0; i < n; ++i) {
+            const float mn[3] = {hmn[i].x, hmn[i].y, hmn[i].z}, mx[3] = {hmx[i].x, hmx[i].y, hmx[i].z};
+            for (int a = 0; a < 3; ++a) { res.root_min[a] = std::min(res.root_min[a], mn[a]); res.root_max[a] = std::max(res.root_max[a], mx[a]); }
+        }
+        res.root = LB_LEAF | 0u; res.n_nodes = 0; res.n_used = 0; res.depth = 0;
+        float ms = 0.f; LCHK(hipEventElapsedTime(&ms, e0, e1)); res.build_ms = ms;
+        cleanup();
+        return NORI_HIP_OK;
+    }
+    unsigned long long *keys, *keys_s; uint32_t *vals, *vals_s;
+    LCHK(alloc((void **) &keys, (size_t) n * 8)); LCHK(alloc((void **) &keys_s, (size_t) n * 8));
+    LCHK(alloc((void **) &vals, (size_t) n * 4)); LCHK(alloc((void **) &vals_s, (size_t) n * 4));
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) cb, keys, vals);
+    LCHK(hipGetLastError());
+    size_t tmp_bytes = 0; void *tmp = nullptr;
+    LCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, (int) n, 0, 63, stream));
+    LCHK(alloc(&tmp, tmp_bytes));
+    LCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, (int) n, 0, 63, stream));
+    uint32_t *left, *right, *first, *last, *parent_inner, *parent_leaf, *arrived; float *nbox;
+    const size_t ni = (size_t) n - 1;
+    LCHK(alloc((void **) &left, ni * 4)); LCHK(alloc((void **) &right, ni * 4)); LCHK(alloc((void **) &first, ni * 4)); LCHK(alloc((void **) &last, ni * 4));
+    LCHK(alloc((void **) &parent_inner, ni * 4)); LCHK(alloc((void **) &parent_leaf, (size_t) n * 4)); LCHK(alloc((void **) &arrived, ni * 4));
+    LCHK(alloc((void **) &nbox, ni * 32));
+    LCHK(hipMemsetAsync(arrived, 0, ni * 4, stream));
+    hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(256), 0, stream, (int) n, (const unsigned long long *) keys_s, left, right, first, last, parent_inner, parent_leaf);
+    LCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) parent_inner, (const uint32_t *) parent_leaf, cb + 6);
+    LCHK(hipGetLastError());
+    uint32_t h_cb[8];
+    LCHK(hipMemcpyAsync(h_cb, cb, sizeof(h_cb), hipMemcpyDeviceToHost, stream));
+    LCHK(hipStreamSynchronize(stream));
+    res.depth = h_cb[6];
+    if (res.depth > max_depth) {
+        err = "lbvh: tree depth " + std::to_string(res.depth) + " exceeds the traversal stack (" + std::to_string(max_depth) + ")";
+        cleanup();
+        return NORI_HIP_EINVAL;
+    }
+    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals_s, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) left,
+                       (const uint32_t *) right, (const uint32_t *) parent_inner, (const uint32_t *) parent_leaf, nbox, arrived);
+    LCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals_s, prims_in, shade_in, prims_out, shade_out);
+    LCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, n, leaf_max, (const uint32_t *) vals_s, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) left,
+                       (const uint32_t *) right, (const uint32_t *) first, (const uint32_t *) last, (const float *) nbox, nodes_out, prims_out, cb + 7);
+    LCHK(hipGetLastError());
+    float h_root[8];
+    LCHK(hipMemcpyAsync(h_root, nbox, 32, hipMemcpyDeviceToHost, stream));
+    LCHK(hipMemcpyAsync(h_cb, cb, sizeof(h_cb), hipMemcpyDeviceToHost, stream));
+    LCHK(hipEventRecord(e1, stream));
+    LCHK(hipStreamSynchronize(stream));
+    for (int a = 0; a < 3; ++a) { res.root_min[a] = h_root[a]; res.root_max[a] = h_root[4 + a]; }
+    res.root = 0u; res.n_nodes = n - 1; res.n_used = h_cb[7];
+    float ms = 0.f; LCHK(hipEventElapsedTime(&ms, e0, e1)); res.build_ms = ms;
+    cleanup();
+    return NORI_HIP_OK;
+#undef LCHK
+}
+
+} // namespace lbvh

@@ -234,12 +234,14 @@ void flattenScene(const Scene *scene, FlatScene &out) {
         }
     }
 
-    // primitive records in leaf (m_indices) order
+    // primitive records in leaf (m_indices) order; in scene order when the tree is left to the device (no host build)
+    const bool built = bvh->isBuilt();
     out.prims.resize(nPrims); out.shade.resize(nPrims);
     for (uint32_t pos = 0; pos < nPrims; ++pos) {
-        uint32_t local = indices[pos]; const uint32_t s = bvh->findShape(local);
+        const uint32_t global = built ? indices[pos] : pos;
+        uint32_t local = global; const uint32_t s = bvh->findShape(local);
         NoriHipPrim &p = out.prims[pos]; std::memset(&p, 0, sizeof(p));
-        p.prim = indices[pos]; p.shape_flags = s;
+        p.prim = global; p.shape_flags = s;
         if (shapes[s]->isSphere()) {
             const Sphere *sp = static_cast<const Sphere *>(shapes[s]); Point3f c = sp->getCenter();
             p.a[0] = c.x; p.a[1] = c.y; p.a[2] = c.z; p.e1[0] = sp->getRadius(); p.shape_flags |= 0x40000000u;
@@ -272,8 +274,13 @@ void flattenScene(const Scene *scene, FlatScene &out) {
         w.left = childRef((uint32_t) i + 1, w.lcount); w.right = childRef(n.w1, w.rcount);
     }
     NoriHipSceneDesc &d = out.desc; std::memset(&d, 0, sizeof(d));
-    uint32_t rootCount; d.root = childRef(0, rootCount);
-    for (int a = 0; a < 3; ++a) { d.root_min[a] = nodes[0].bmin[a]; d.root_max[a] = nodes[0].bmax[a]; }
+    if (built) {
+        uint32_t rootCount; d.root = childRef(0, rootCount);
+        for (int a = 0; a < 3; ++a) { d.root_min[a] = nodes[0].bmin[a]; d.root_max[a] = nodes[0].bmax[a]; }
+    } else {
+        d.root = NORI_HIP_NO_CHILD;                          // for nori_hip_upload_scene_build
+        for (int a = 0; a < 3; ++a) { d.root_min[a] = bvh->getBoundingBox().min[a]; d.root_max[a] = bvh->getBoundingBox().max[a]; }
+    }
     d.n_nodes = (uint32_t) out.nodes.size(); d.nodes = out.nodes.empty() ? nullptr : out.nodes.data();
     d.n_prims = nPrims; d.prims = out.prims.data(); d.shade_prims = out.shade.data();
     d.n_shapes = (uint32_t) out.shapes.size(); d.shapes = out.shapes.data();

@@ -15,19 +15,27 @@ static void hipCheck(int rc, const char *what) {
 }
 
 /// GPU path tracer with multiple importance sampling.  Registered as "path_mis" (so existing scene files select
-/// it unchanged) and as "path_mis_hip".  Properties: device (int, default 0 or $NORI_HIP_DEVICE).
+/// it unchanged) and as "path_mis_hip".  Properties: device (int, default 0 or $NORI_HIP_DEVICE); bvh (string, "host" =
+/// the reference's SAH tree built by Scene::activate (default) or "device" = a linear BVH built on the GPU at preprocess(),
+/// default $NORI_HIP_BVH).
 class PathMisHip : public GpuIntegrator {
 public:
     explicit PathMisHip(const PropertyList &props) {
         const char *env = getenv("NORI_HIP_DEVICE");
         m_device = props.getInteger("device", env ? atoi(env) : 0);
+        const char *benv = getenv("NORI_HIP_BVH");
+        std::string bvh = props.getString("bvh", benv ? benv : "host");
+        if (bvh != "host" && bvh != "device") throw NoriException::format("path_mis: unknown bvh mode \"%s\" (host, device)", bvh.c_str());
+        m_deviceBvh = bvh == "device";
     }
+    bool buildsOwnBVH() const override { return m_deviceBvh; }
     ~PathMisHip() override { if (m_ctx) nori_hip_destroy(m_ctx); }
     void preprocess(const Scene *scene) override {
         flattenScene(scene, m_flat);
         if (m_flat.desc.n_emitters == 0) throw NoriException("path_mis: the scene has no emitters");
         if (!m_ctx) hipCheck(nori_hip_create(m_device, &m_ctx), "nori_hip_create");
-        hipCheck(nori_hip_upload_scene(m_ctx, &m_flat.desc), "nori_hip_upload_scene");
+        if (m_deviceBvh) hipCheck(nori_hip_upload_scene_build(m_ctx, &m_flat.desc), "nori_hip_upload_scene_build");
+        else hipCheck(nori_hip_upload_scene(m_ctx, &m_flat.desc), "nori_hip_upload_scene");
     }
     void render(const Scene *scene, int spp_begin, int spp_end) override {
         if (!m_ctx) preprocess(scene);
@@ -47,7 +55,7 @@ public:
     std::string toString() const override { return "PathMisIntegrator[backend=hip/gfx950]"; }
 private:
     void need() const { if (!m_ctx) throw NoriException("path_mis: preprocess() has not run"); }
-    int m_device = 0; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
+    int m_device = 0; bool m_deviceBvh = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
 };
 static NoriObject *PathMisHip_create(const PropertyList &l) { return new PathMisHip(l); }
 static struct PathMisHip_reg { PathMisHip_reg() { NoriObjectFactory::registerClass("path_mis", PathMisHip_create); NoriObjectFactory::registerClass("path_mis_hip", PathMisHip_create); } } PathMisHip_reg_;

@@ -424,8 +424,8 @@ NORI_REGISTER_CLASS(Independent, "independent")
 Scene::Scene(const PropertyList &) { m_bvh = new BVH(); }
 Scene::~Scene() { delete m_bvh; delete m_sampler; delete m_camera; delete m_integrator; for (auto e : m_emitters) delete e; }
 void Scene::activate() {
-    m_bvh->build();
     if (!m_integrator) throw NoriException("No integrator was specified!");
+    if (!m_integrator->buildsOwnBVH()) m_bvh->build();      // src/scene.cpp:42-43; otherwise the device builds a tree at preprocess()
     if (!m_camera) throw NoriException("No camera was specified!");
     if (!m_sampler) { m_sampler = static_cast<Sampler *>(NoriObjectFactory::createInstance("independent", PropertyList())); m_sampler->activate(); }
 }

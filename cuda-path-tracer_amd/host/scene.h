@@ -143,6 +143,7 @@ public:
     ~BVH();
     void addShape(Shape *shape);
     void build(int threads = 0);
+    bool isBuilt() const { return !m_nodes.empty(); }
     uint32_t getPrimitiveCount() const { return m_shapeOffset.back(); }
     const std::vector<Shape *> &getShapes() const { return m_shapes; }
     const std::vector<uint32_t> &getShapeOffsets() const { return m_shapeOffset; }
@@ -164,6 +165,8 @@ class Integrator : public NoriObject {
 public:
     EClassType getClassType() const override { return EIntegrator; }
     virtual void preprocess(const Scene *) {}
+    /// true: the integrator builds the acceleration structure itself (on the device); Scene::activate then skips the host SAH build
+    virtual bool buildsOwnBVH() const { return false; }
     /// Accumulates samples [spp_begin, spp_end) of every pixel into the integrator's film
     virtual void render(const Scene *scene, int spp_begin, int spp_end) = 0;
     /// rows x cols x 4 float film (ImageBlock layout) and its border

@@ -74,6 +74,8 @@ def hip_lib():
         L.nori_hip_create.argtypes = [i32, C.POINTER(vp)]
         L.nori_hip_destroy.argtypes = [vp]
         L.nori_hip_upload_scene.argtypes = [vp, vp]
+        L.nori_hip_upload_scene_build.argtypes = [vp, vp]
+        L.nori_hip_build_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.nori_hip_trace.argtypes = [vp, vp, sz, i32, vp, vp]
         L.nori_hip_trace_device.argtypes = [vp, vp, sz, i32, vp]
         L.nori_hip_camera_rays.argtypes = [vp, vp, sz, vp]
@@ -167,6 +169,15 @@ class Context:
 
     def upload(self, desc_ptr):
         _hchk(self.L.nori_hip_upload_scene(self.h, C.cast(desc_ptr, C.c_void_p)))
+
+    def upload_build(self, desc_ptr):
+        """upload with the tree built on the device (nori_hip_upload_scene_build)"""
+        _hchk(self.L.nori_hip_upload_scene_build(self.h, C.cast(desc_ptr, C.c_void_p)))
+
+    def build_info(self):
+        a, b, c, ms = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()
+        _hchk(self.L.nori_hip_build_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(ms)))
+        return dict(n_nodes=a.value, n_used=b.value, depth=c.value, build_ms=ms.value)
 
     def trace(self, rays, any_hit=False, full=False):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

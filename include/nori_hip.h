@@ -176,6 +176,17 @@ int nori_hip_destroy(NoriHipContext *ctx);
  * cudaMemcpy marshalling of cuda/CudaRender.cpp:80-98 and ImageBlock::init (src/block.cpp:38-74). */
 int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *desc);
 
+/* Same, but the library builds the tree itself, on the device: a linear BVH (Morton order of the records' box centres,
+ * Karras 2012) with at most NORI_HIP_LBVH_LEAF (default 4) records per leaf.  desc->prims / shade_prims may come in any
+ * order (bit 31 of shape_flags is ignored); nodes, n_nodes, root, root_min and root_max are ignored.  No counterpart
+ * in the reference, whose SAH build (src/bvh.cpp:54-306) runs on the host and is what nori_hip_upload_scene expects to
+ * have been done: this entry is SURVEY §8f's "GPU BVH build" for scenes whose host build would dominate (10 M
+ * triangles: 14 s).  The tree is not the reference's: closest hits name the same primitive except where two
+ * primitives tie in t, any-hit answers are identical; traversal enters the nearer child first.
+ * nori_hip_build_info: size of the node array, nodes in use, tree depth, device time of the build. */
+int nori_hip_upload_scene_build(NoriHipContext *ctx, const NoriHipSceneDesc *desc);
+int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used, uint32_t *depth, double *build_ms);
+
 /* Closest-hit (any_hit = 0) or any-hit (any_hit != 0: hits[i].prim is 1 when occluded, NORI_HIP_MISS otherwise)
  * queries for n host rays.  Replaces Scene::rayIntersect -> BVH::rayIntersect (src/bvh.cpp:404-463) including
  * Shape::setHitInformation's uv (src/mesh.cpp:137-141).  `full`, if not NULL, receives 16 floats per ray:
