@@ -12,8 +12,8 @@ namespace lbvh {
 
 struct Result {
     uint32_t root;                 // child reference of the root
-    uint32_t n_nodes;              // size of the node array (n_prims - 1; entries below collapsed leaves are unused)
-    uint32_t n_used, depth;        // inner nodes in use, depth of the tree (levels of inner nodes)
+    uint32_t n_nodes;              // nodes in the (packed) node array
+    uint32_t n_used, depth;        // = n_nodes; depth of the uncollapsed tree (levels of inner nodes)
     float root_min[3], root_max[3];
     double build_ms;               // device time of the whole build (HIP events)
 };

@@ -12,6 +12,7 @@
 //   k_reorder   records into sorted (leaf) order
 //   k_emit      one thread per inner node: the 64-byte node with both children's boxes; subtrees of at most
 //               `leaf_max` records become one leaf (their records are contiguous in sorted order)
+//   hipcub scan + k_compact   the nodes in use, packed (the nodes inside collapsed subtrees are dropped)
 #include "nori_lbvh.h"
 #include <hipcub/hipcub.hpp>
 #include <vector>
@@ -167,16 +168,11 @@ __global__ __launch_bounds__(256) void k_reorder(uint32_t n, const uint32_t *val
 
 __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t leaf_max, const uint32_t *vals, const float4 *pmin, const float4 *pmax, const uint32_t *left,
                                               const uint32_t *right, const uint32_t *first, const uint32_t *last, const float *nbox, NoriHipNode *nodes,
-                                              NoriHipPrim *pout, uint32_t *n_used) {
+                                              NoriHipPrim *pout, uint32_t *used) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     NoriHipNode w;
-    if (i != 0u && last[i] - first[i] + 1u <= leaf_max) {                 // inside a collapsed subtree: never referenced
-        for (int a = 0; a < 3; ++a) { w.lmin[a] = w.lmax[a] = w.rmin[a] = w.rmax[a] = 0.f; }
-        w.left = w.right = NORI_HIP_NO_CHILD; w.lcount = w.rcount = 0;
-        nodes[i] = w;
-        return;
-    }
+    if (i != 0u && last[i] - first[i] + 1u <= leaf_max) { used[i] = 0u; return; }   // inside a collapsed subtree: never referenced
     for (int side = 0; side < 2; ++side) {
         const uint32_t c = side ? right[i] : left[i];
         float *mn = side ? w.rmin : w.lmin, *mx = side ? w.rmax : w.lmax;
@@ -197,7 +193,17 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t leaf_max, con
         if (side) { w.right = ref; w.rcount = count; } else { w.left = ref; w.lcount = count; }
     }
     nodes[i] = w;
-    atomicAdd(n_used, 1u);
+    used[i] = 1u;
+}
+
+// the nodes in use, packed in their old order (so the root stays node 0 and neighbours in Morton order stay neighbours)
+__global__ __launch_bounds__(256) void k_compact(uint32_t n_inner, const uint32_t *used, const uint32_t *new_index, const NoriHipNode *nodes, NoriHipNode *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner || !used[i]) return;
+    NoriHipNode w = nodes[i];
+    if (!(w.left & LB_LEAF)) w.left = new_index[w.left];
+    if (!(w.right & LB_LEAF)) w.right = new_index[w.right];
+    out[new_index[i]] = w;
 }
 
 __global__ void k_mark_last(NoriHipPrim *pout, uint32_t pos) { pout[pos].shape_flags |= 0x80000000u; }
@@ -278,16 +284,27 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
     LCHK(hipGetLastError());
     hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals_s, prims_in, shade_in, prims_out, shade_out);
     LCHK(hipGetLastError());
+    NoriHipNode *nodes_tmp; uint32_t *used, *new_index;
+    LCHK(alloc((void **) &nodes_tmp, ni * sizeof(NoriHipNode))); LCHK(alloc((void **) &used, ni * 4)); LCHK(alloc((void **) &new_index, ni * 4));
     hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, n, leaf_max, (const uint32_t *) vals_s, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) left,
-                       (const uint32_t *) right, (const uint32_t *) first, (const uint32_t *) last, (const float *) nbox, nodes_out, prims_out, cb + 7);
+                       (const uint32_t *) right, (const uint32_t *) first, (const uint32_t *) last, (const float *) nbox, nodes_tmp, prims_out, used);
     LCHK(hipGetLastError());
+    size_t scan_bytes = 0; void *scan_tmp = nullptr;
+    LCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, used, new_index, (int) ni, stream));
+    LCHK(alloc(&scan_tmp, scan_bytes));
+    LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, used, new_index, (int) ni, stream));
+    hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) used, (const uint32_t *) new_index, (const NoriHipNode *) nodes_tmp, nodes_out);
+    LCHK(hipGetLastError());
+    uint32_t h_last[2];
+    LCHK(hipMemcpyAsync(&h_last[0], used + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
+    LCHK(hipMemcpyAsync(&h_last[1], new_index + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
     float h_root[8];
     LCHK(hipMemcpyAsync(h_root, nbox, 32, hipMemcpyDeviceToHost, stream));
     LCHK(hipMemcpyAsync(h_cb, cb, sizeof(h_cb), hipMemcpyDeviceToHost, stream));
     LCHK(hipEventRecord(e1, stream));
     LCHK(hipStreamSynchronize(stream));
     for (int a = 0; a < 3; ++a) { res.root_min[a] = h_root[a]; res.root_max[a] = h_root[4 + a]; }
-    res.root = 0u; res.n_nodes = n - 1; res.n_used = h_cb[7];
+    res.root = 0u; res.n_used = h_last[0] + h_last[1]; res.n_nodes = res.n_used;
     float ms = 0.f; LCHK(hipEventElapsedTime(&ms, e0, e1)); res.build_ms = ms;
     cleanup();
     return NORI_HIP_OK;
