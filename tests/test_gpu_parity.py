@@ -442,3 +442,40 @@ def test_device_built_bvh_gives_the_reference_hits(name):
     close = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(2)
     assert close.mean() > 0.999, close.mean()
     hd.close(); hs.close()
+
+
+def test_device_built_bvh_edge_cases():
+    """tiny inputs (the whole scene is one leaf: root is a leaf reference, no node), exactly leaf_max + 1 records, and many
+    records with the same Morton code (coincident triangles: keys are told apart by position)"""
+    def scene(tris_per_quad_stack, copies):
+        sb = NH.SceneBuilder()
+        quad_v = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+        quad_f = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)[:tris_per_quad_stack]
+        for k in range(copies):
+            sb.add_mesh("floor%d" % k, quad_v, quad_f, color=(0.5, 0.5, 0.5))
+        sb.add_mesh("light", quad_v * 0.3 + np.array([0, 2, 0], np.float32), quad_f[:, ::-1][:1], radiance=(10, 10, 10))
+        sb.set_camera((0, 3, 3), (0, 0, 0), (0, 1, 0), 50.0, 32, 32)
+        return sb
+    rng = np.random.default_rng(4)
+    for tris, copies in ((1, 1), (2, 2), (2, 300)):
+        os.environ["NORI_HIP_BVH"] = "device"
+        try:
+            hd = scene(tris, copies).finish(spp=1)
+            cd = hd.preprocess()
+        finally:
+            del os.environ["NORI_HIP_BVH"]
+        hs = scene(tris, copies).finish(spp=1)
+        cs = hs.preprocess()
+        n = hd.info()["prims"]
+        bi = cd.build_info()
+        assert n == tris * copies + 1
+        assert (bi["n_nodes"] == 0) == (n <= 4), (n, bi)
+        rays = cs.camera_rays((rng.random((2000, 2)) * 32).astype(np.float32))
+        a, b = cs.trace(rays), cd.trace(rays)
+        assert np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32))      # coincident copies: the same t, whichever copy wins
+        assert np.array_equal(a["prim"] == NH.MISS, b["prim"] == NH.MISS) and (b["prim"] != NH.MISS).any()
+        assert np.array_equal(cs.trace(rays, any_hit=True)["prim"], cd.trace(rays, any_hit=True)["prim"])
+        cd.clear_film(); cd.render(0, 4)
+        cs.clear_film(); cs.render(0, 4)
+        assert np.allclose(cs.read_film(), cd.read_film(), rtol=1e-4, atol=1e-5)  # identical BSDFs on every copy: ties do not show
+        hd.close(); hs.close()
