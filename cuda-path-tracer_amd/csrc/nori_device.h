@@ -165,7 +165,7 @@ struct CachedNodes {
 // Trav is the traversal as a resumable state machine whose steps contain no data-dependent loops: box_step()
 // visits one 64-byte node, prim_step() tests ONE leaf record, pop_step() takes one entry off the stack.  A kernel
 // runs the steps for the lanes that are in the matching state; the queue kernels choose per trip which step is
-// worth running for the wave (see k_trace_queue).  `cur` encodes the state:
+// worth running for the wave (see k_trace_pool).  `cur` encodes the state:
 //   < ND_POP            inner node index            (box_step)
 //   ND_POP              needs an entry of the stack (pop_step)
 //   ND_DONE             traversal finished

@@ -774,6 +774,7 @@ struct NoriHipContext {
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
     lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
     uint32_t lbvh_leaf = 4;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF)
+    float lbvh_big = 0.25f;           // records longer than this fraction of the scene get their own subtree (NORI_HIP_LBVH_BIG, 0 = off)
     float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
     unsigned long long *d_counter = nullptr; DevStats *d_stats = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -800,7 +801,7 @@ struct NoriHipContext {
     bool trace_cache = false;         // (unused: the trace stage no longer caches nodes in LDS; kept so the environment knob parses)
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
-    int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_queue step thresholds (lanes)
+    int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_pool step thresholds (lanes), NORI_HIP_THR
     // adds the elapsed time of the recorded extend launches to ext_ms_acc (waits for them)
     int fold_ext_events() {
         for (size_t k = 0; k + 1 < ext_used; k += 2) {
@@ -845,6 +846,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipMemset(c->d_stats, 0, ND_STRIPES * sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
+    if (const char *e = getenv("NORI_HIP_LBVH_BIG")) { float v = (float) atof(e); if (v >= 0.f) c->lbvh_big = v; }
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
@@ -953,7 +955,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         hipError_t e3_ = hipMalloc((void **) &ctx->d_nodes, (size_t) std::max<uint32_t>(d->n_prims - 1, 1u) * sizeof(NoriHipNode));
         std::string lerr;
         rc = (e1_ != hipSuccess || e2_ != hipSuccess || e3_ != hipSuccess) ? NORI_HIP_EDEVICE
-             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf, ND_STACK - 2, ctx->lbvh, lerr);
+             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf, ctx->lbvh_big, ND_STACK - 2, ctx->lbvh, lerr);
         hipFree(tmp_prims); hipFree(tmp_shade);
         if (rc) { ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
         root = ctx->lbvh.root;

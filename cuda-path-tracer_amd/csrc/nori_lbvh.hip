@@ -65,19 +65,23 @@ __device__ __forceinline__ unsigned long long spread21(unsigned long long x) {  
     return x;
 }
 
-__global__ __launch_bounds__(256) void k_morton(uint32_t n, const float4 *pmin, const float4 *pmax, const uint32_t *cbounds, unsigned long long *keys, uint32_t *vals) {
+// Records whose box is longer than `big` times the extent of the centre bounds on some axis get the top key bit: they
+// sort behind all others and the hierarchy splits them off at the root, into a subtree of their own.  (A room-sized
+// wall triangle that shares a Morton cell with millimetre-sized ones would otherwise inflate every box above it.)
+__global__ __launch_bounds__(256) void k_morton(uint32_t n, const float4 *pmin, const float4 *pmax, const uint32_t *cbounds, float big, unsigned long long *keys, uint32_t *vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 a = pmin[i], b = pmax[i];
-    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
-    unsigned long long code = 0;
+    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)}, e[3] = {b.x - a.x, b.y - a.y, b.z - a.z};
+    unsigned long long code = 0; bool large = false;
     for (int k = 0; k < 3; ++k) {
         const float lo = o2f(cbounds[k]), hi = o2f(cbounds[3 + k]);
         float t = (hi > lo) ? (c[k] - lo) / (hi - lo) : 0.f;
         t = fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
         code |= spread21((unsigned long long) t) << (2 - k);
+        large = large || (big > 0.f && e[k] > big * (hi - lo));
     }
-    keys[i] = code; vals[i] = i;
+    keys[i] = code | (large ? 0x8000000000000000ull : 0ull); vals[i] = i;
 }
 
 // length of the common prefix of the keys at sorted positions i and j; -1 outside the array
@@ -211,7 +215,7 @@ __global__ void k_mark_last(NoriHipPrim *pout, uint32_t pos) { pout[pos].shape_f
 } // namespace
 
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
-          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, uint32_t max_depth, Result &res, std::string &err) {
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, Result &res, std::string &err) {
     std::vector<void *> owned; hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() { for (void *p : owned) (void) hipFree(p); owned.clear(); if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); e0 = e1 = nullptr; };
 #define LCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); cleanup(); return NORI_HIP_EDEVICE; } } while (0)
@@ -254,12 +258,12 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
     unsigned long long *keys, *keys_s; uint32_t *vals, *vals_s;
     LCHK(alloc((void **) &keys, (size_t) n * 8)); LCHK(alloc((void **) &keys_s, (size_t) n * 8));
     LCHK(alloc((void **) &vals, (size_t) n * 4)); LCHK(alloc((void **) &vals_s, (size_t) n * 4));
-    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) cb, keys, vals);
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) cb, big, keys, vals);
     LCHK(hipGetLastError());
     size_t tmp_bytes = 0; void *tmp = nullptr;
-    LCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, (int) n, 0, 63, stream));
+    LCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, (int) n, 0, 64, stream));
     LCHK(alloc(&tmp, tmp_bytes));
-    LCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, (int) n, 0, 63, stream));
+    LCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, (int) n, 0, 64, stream));
     uint32_t *left, *right, *first, *last, *parent_inner, *parent_leaf, *arrived; float *nbox;
     const size_t ni = (size_t) n - 1;
     LCHK(alloc((void **) &left, ni * 4)); LCHK(alloc((void **) &right, ni * 4)); LCHK(alloc((void **) &first, ni * 4)); LCHK(alloc((void **) &last, ni * 4));

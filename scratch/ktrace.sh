@@ -11,7 +11,7 @@ python3 - $tag <<'PY'
 import csv, glob, sys
 f = glob.glob('gpurun_out/kt_%s/*/*kernel_stats.csv' % sys.argv[1])[0]
 for r in csv.DictReader(open(f)):
-    n = r['Name']; short = n.split('(')[0][-40:]
-    if 'k_trace_queue' in n: short = 'k_trace_queue<' + n.split('k_trace_queue<')[1].split('>')[0] + '>'
+    n = r['Name']; short = n.split('(anonymous namespace)::')[-1].split('(')[0][-40:] if '::' in n else n[:40]
+    if 'k_trace_pool' in n: short = 'k_trace_pool<' + n.split('k_trace_pool<')[1].split('>')[0] + '>'
     print('%-45s calls %5s  total/render %8.3f ms  avg %9.1f us  max %9.1f us' % (short, r['Calls'], float(r['TotalDurationNs']) / 4e6, float(r['AverageNs']) / 1e3, float(r['MaxNs']) / 1e3))
 PY
