@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--c4-side", type=int, default=0)
+    ap.add_argument("--partition", default="spp", choices=["spp", "tiles"],
+                    help="spp: every rank renders its own spp slice of the whole image (weak scaling, default); tiles: the ranks share one image by interleaved 32-row bands (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +129,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     import torch
     import nori_hip as NH
-    from nori_hip.partition import spp_slice, allreduce_film
+    from nori_hip.partition import spp_slice, tile_bands, allreduce_film
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -151,11 +153,16 @@ def main():
     bi = ctx.build_info()
     film = film_tensor(ctx, torch) if world > 1 else None
     spp = w["spp"]
-    samples_per_step = w["width"] * w["height"] * spp
+    tiles = args.partition == "tiles"
+    samples_per_step = w["width"] * w["height"] * spp                 # per rank (spp slices) or per job (tiles)
 
     def step(k):
         ctx.clear_film()
-        ctx.render(*spp_slice(rank, world, spp))          # this rank's spp slice
+        if tiles:
+            for y0, y1 in tile_bands(rank, world, w["height"]):      # this rank's bands, all samples
+                ctx.render(0, spp, tile=(0, y0, w["width"], y1))
+        else:
+            ctx.render(*spp_slice(rank, world, spp))      # this rank's spp slice
         if film is not None:
             ctx.synchronize()                             # film complete before the collective reads it
             allreduce_film(film, dist)
@@ -199,7 +206,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_samples = samples_per_step * args.steps * world
+    total_samples = samples_per_step * args.steps * (1 if tiles else world)
     rays = (st["closest_rays"] + st["shadow_rays"]) / args.steps            # this rank, per step
     # algorithmic bytes per step: 32 B per node box tested + 40 B per primitive tested
     # + 44 B ray in + 16 B hit out per ray + 2 x 16 B film read-modify-write per camera sample
@@ -221,9 +228,9 @@ def main():
     out = {
         "metric": "Msamples/s (path_mis, whole node)", "value": round(total_samples / dt / 1e6, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if w["xml"] is None else "reference scene files (scenes/)",
+        "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if w["xml"] is None else "reference scene files (scenes/)",
         "config": {"workload": w["name"], "width": w["width"], "height": w["height"], "spp_per_gpu": spp, "triangles": info["prims"],
-                   "bvh_nodes_64B": info["wide_nodes"], "partition": "spp slices, RCCL all-reduce of the fp32 film" if world > 1 else "single GPU",
+                   "bvh_nodes_64B": info["wide_nodes"], "partition": ("interleaved 32-row bands" if tiles else "spp slices") + ", RCCL all-reduce of the fp32 film" if world > 1 else "single GPU",
                    "scene_load_s": round(load_s, 2), "bvh_build_s": round(hs.bvh_build_seconds(), 3),
                    "bvh": ("device LBVH, %.1f ms, %d of %d nodes used, depth %d" % (bi["build_ms"], bi["n_used"], bi["n_nodes"], bi["depth"])) if bi["n_nodes"] or bi["build_ms"] else "host SAH (reference order)"},
         "mrays_per_s": round(rays * world * args.steps / dt / 1e6, 2),

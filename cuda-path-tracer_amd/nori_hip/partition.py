@@ -29,6 +29,17 @@ def split_spp(total_spp, world):
     return out
 
 
+def tile_bands(rank, world, height, band=32):
+    """strong-scaling split by image tiles (SURVEY §8e ii): the rows of `rank` as [y0, y1) bands of `band` rows (the
+    reference's block size, NORI_BLOCK_SIZE), dealt round-robin so that every rank gets rows from all over the image.
+    Bands of different ranks are disjoint, so summing the films (the same all-reduce as for spp slices) assembles the
+    image; every rank renders all samples of its pixels."""
+    if world < 1 or not (0 <= rank < world) or height < 1 or band < 1:
+        raise ValueError("bad partition: rank %r of %r, height %r, band %r" % (rank, world, height, band))
+    n_bands = (height + band - 1) // band
+    return [(k * band, min(height, (k + 1) * band)) for k in range(rank, n_bands, world)]
+
+
 def allreduce_film(film, dist):
     """sum the ranks' films in place (torch tensor, any device); a no-op without a process group.  The caller has
     synchronised the render stream before (the collective runs on torch's stream and reads the film); on return the

@@ -133,6 +133,14 @@ def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
     parts = ctx.read_film()
     assert np.array_equal(parts[:, :, 3], whole[:, :, 3])
     assert np.allclose(parts, whole, rtol=1e-4, atol=1e-5)                    # fp32 atomics: order differs, values do not
+    # the tile partition of bench.py --partition tiles: three ranks' interleaved 32-row bands, rendered one after the other
+    from nori_hip.partition import tile_bands
+    ctx.clear_film()
+    for r in range(3):
+        for y0, y1 in tile_bands(r, 3, H, 32):
+            ctx.render(0, 8, tile=(0, y0, W, y1))
+    bands = ctx.read_film()
+    assert np.array_equal(bands[:, :, 3], whole[:, :, 3]) and np.allclose(bands, whole, rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["cbox_mirror_microfacet", "table", "dragon", "cbox_subsurface", "texture_bump"])
