@@ -4,6 +4,8 @@
 //            src/rfilter.cpp, src/scene.cpp, src/consttexture.cpp.
 #include "scene.h"
 #include <cstring>
+#include <cstdio>
+#include <sys/stat.h>
 #include <fstream>
 #include <sstream>
 #include <unordered_map>
@@ -70,6 +72,12 @@ public:
         std::ifstream is(filename);
         if (is.fail()) throw NoriException::format("Unable to open OBJ file \"%s\"!", filename.c_str());
         Transform trafo = propList.getTransform("toWorld", Transform());
+        // Binary cache of the parsed, transformed, de-duplicated arrays (text-parsing a 10 M-triangle OBJ
+        // dominates start-up).  Opt-in: $NORI_HIP_MESH_CACHE=1 reads and writes "<file>.noricache" next to the OBJ; an entry
+        // is used only if the OBJ's size and modification time and the toWorld matrix are the ones it was made from.
+        const char *cenv = getenv("NORI_HIP_MESH_CACHE");
+        const bool useCache = cenv && atoi(cenv) != 0;
+        if (useCache && loadCache(filename, trafo)) { m_name = filename; return; }
         struct Key { uint32_t p, n, uv; bool operator==(const Key &o) const { return p == o.p && n == o.n && uv == o.uv; } };
         struct KeyHash { size_t operator()(const Key &k) const { size_t h = k.p; h = h * 37 + k.uv; h = h * 37 + k.n; return h; } };
         std::vector<Point3f> positions, normals; std::vector<Point2f> texcoords; std::vector<Key> vertices;
@@ -109,6 +117,48 @@ public:
         if (!texcoords.empty()) { m_UV.resize(2 * vertices.size());
             for (size_t i = 0; i < vertices.size(); ++i) { const Point2f &t = texcoords.at(vertices[i].uv - 1); m_UV[2 * i] = t.x; m_UV[2 * i + 1] = t.y; } }
         m_name = filename;
+        if (useCache) saveCache(filename, trafo);
+    }
+private:
+    struct CacheHeader { char magic[8]; uint64_t srcSize; int64_t srcMtimeNs; float trafo[16]; uint64_t nV, nF; uint32_t hasN, hasUV; float bbox[6]; };
+    static bool sourceStamp(const std::string &filename, uint64_t &size, int64_t &mtimeNs) {
+        struct stat st;
+        if (stat(filename.c_str(), &st) != 0) return false;
+        size = (uint64_t) st.st_size; mtimeNs = (int64_t) st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+        return true;
+    }
+    bool loadCache(const std::string &filename, const Transform &trafo) {
+        std::ifstream f(filename + ".noricache", std::ios::binary);
+        CacheHeader h; uint64_t size; int64_t mtime;
+        if (!f || !f.read(reinterpret_cast<char *>(&h), sizeof(h)) || std::memcmp(h.magic, "NORIMSH1", 8) != 0) return false;
+        if (!sourceStamp(filename, size, mtime) || size != h.srcSize || mtime != h.srcMtimeNs || std::memcmp(h.trafo, trafo.m, 64) != 0) return false;
+        if (h.nV == 0 || h.nF == 0 || h.nV > (1ull << 32) || h.nF > (1ull << 32)) return false;
+        std::vector<float> V(3 * h.nV), N(h.hasN ? 3 * h.nV : 0), UV(h.hasUV ? 2 * h.nV : 0); std::vector<uint32_t> F(3 * h.nF);
+        auto rd = [&](void *p, size_t bytes) { return bytes == 0 || (bool) f.read(reinterpret_cast<char *>(p), (std::streamsize) bytes); };
+        if (!rd(V.data(), V.size() * 4) || !rd(N.data(), N.size() * 4) || !rd(UV.data(), UV.size() * 4) || !rd(F.data(), F.size() * 4)) return false;
+        for (uint32_t i : F) if (i >= h.nV) return false;
+        m_V.swap(V); m_N.swap(N); m_UV.swap(UV); m_F.swap(F);
+        m_bbox.min = Point3f(h.bbox[0], h.bbox[1], h.bbox[2]); m_bbox.max = Point3f(h.bbox[3], h.bbox[4], h.bbox[5]);
+        return true;
+    }
+    void saveCache(const std::string &filename, const Transform &trafo) const {
+        CacheHeader h; std::memset(&h, 0, sizeof(h)); std::memcpy(h.magic, "NORIMSH1", 8);
+        if (!sourceStamp(filename, h.srcSize, h.srcMtimeNs)) return;
+        std::memcpy(h.trafo, trafo.m, 64);
+        h.nV = m_V.size() / 3; h.nF = m_F.size() / 3; h.hasN = !m_N.empty(); h.hasUV = !m_UV.empty();
+        for (int a = 0; a < 3; ++a) { h.bbox[a] = m_bbox.min[a]; h.bbox[3 + a] = m_bbox.max[a]; }
+        const std::string tmp = filename + ".noricache.tmp";
+        {
+            std::ofstream f(tmp, std::ios::binary);
+            if (!f) return;                                  // read-only scene directory: no cache, no error
+            f.write(reinterpret_cast<const char *>(&h), sizeof(h));
+            f.write(reinterpret_cast<const char *>(m_V.data()), (std::streamsize) m_V.size() * 4);
+            f.write(reinterpret_cast<const char *>(m_N.data()), (std::streamsize) m_N.size() * 4);
+            f.write(reinterpret_cast<const char *>(m_UV.data()), (std::streamsize) m_UV.size() * 4);
+            f.write(reinterpret_cast<const char *>(m_F.data()), (std::streamsize) m_F.size() * 4);
+            if (!f) { std::remove(tmp.c_str()); return; }
+        }
+        std::rename(tmp.c_str(), (filename + ".noricache").c_str());       // atomic: readers never see a partial file
     }
 };
 NORI_REGISTER_CLASS(WavefrontOBJ, "obj")

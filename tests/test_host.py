@@ -185,3 +185,41 @@ def test_procedural_scene_builder_and_parallel_bvh_build_is_deterministic():
         res.append((n32.copy(), idx.copy()))
         assert hs.info()["prims"] == len(F) + 2
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_binary_mesh_cache_round_trip(tmp_path):
+    """NORI_HIP_MESH_CACHE=1: the second load reads "<obj>.noricache" instead of parsing the text and
+    yields the same arrays, BVH and tables; a cache made from another toWorld or an older OBJ is ignored."""
+    import shutil
+    d = tmp_path / "scene"
+    shutil.copytree(os.path.join(SCENES, "cbox"), d)
+    xml = str(d / "cbox_path_mis.xml")
+    plain = NH.HostScene(xml, 32, 32, 1)
+    os.environ["NORI_HIP_MESH_CACHE"] = "1"
+    try:
+        first = NH.HostScene(xml, 32, 32, 1)                       # parses, writes the caches
+        caches = sorted(p.name for p in (d / "meshes").glob("*.noricache"))
+        assert len(caches) == 4, caches
+        # replace the OBJ text behind one cache entry by comments of the same size and restore its mtime: a load that
+        # parsed the text would now see an empty mesh, a cached load cannot notice
+        victim = d / "meshes" / caches[0].replace(".noricache", "")
+        st = os.stat(victim)
+        data = victim.read_bytes()
+        victim.write_bytes(b"#" * len(data))
+        os.utime(victim, ns=(st.st_atime_ns, st.st_mtime_ns))
+        second = NH.HostScene(xml, 32, 32, 1)                      # reads the caches
+        # and a changed file (new mtime) is parsed again
+        victim.write_bytes(data)
+        os.utime(victim, ns=(st.st_atime_ns, st.st_mtime_ns + 10**9))
+        third = NH.HostScene(xml, 32, 32, 1)
+    finally:
+        del os.environ["NORI_HIP_MESH_CACHE"]
+    for hs in (first, second, third):
+        assert hs.info() == plain.info()
+        for s in range(plain.info()["shapes"]):
+            a, b = plain.mesh(s), hs.mesh(s)
+            for k in ("V", "F", "cdf", "N", "UV"):
+                assert (a[k] is None) == (b[k] is None) and (a[k] is None or np.array_equal(a[k], b[k])), (s, k)
+        n0, i0 = plain.bvh32()
+        n1, i1 = hs.bvh32()
+        assert np.array_equal(n0, n1) and np.array_equal(i0, i1)
