@@ -487,3 +487,32 @@ def test_device_built_bvh_edge_cases():
         cs.clear_film(); cs.render(0, 4)
         assert np.allclose(cs.read_film(), cd.read_film(), rtol=1e-4, atol=1e-5)  # identical BSDFs on every copy: ties do not show
         hd.close(); hs.close()
+
+
+def test_film_tensor_and_rccl_all_reduce_on_the_device_film(loaded):
+    """the N > 1 leg of bench.py, as far as one GPU can run it: the film wrapped as a torch tensor without a copy
+    (nori_hip_film_device_ptr) and summed in place by an RCCL all-reduce (a one-rank group here)"""
+    import torch
+    import torch.distributed as dist
+    sys_path_bench = os.path.dirname(SCENES)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(sys_path_bench, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from nori_hip.partition import allreduce_film
+    hs, ctx = loaded("cbox", 64, 64)
+    ctx.clear_film(); ctx.render(0, 2); ctx.synchronize()
+    before = ctx.read_film()
+    film = bench.film_tensor(ctx, torch)
+    assert film.is_cuda and film.numel() == before.size
+    assert np.array_equal(film.cpu().numpy().reshape(before.shape), before)
+    film.mul_(2.0); torch.cuda.synchronize()                                    # in place: the library sees it
+    assert np.array_equal(ctx.read_film(), before * 2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        allreduce_film(film, dist)
+        dist.barrier(); torch.cuda.synchronize()
+        assert np.array_equal(ctx.read_film(), before * 2)                      # sum over one rank
+    finally:
+        dist.destroy_process_group()
