@@ -818,6 +818,37 @@ __device__ __forceinline__ bool path_bounce(const DevScene &sc, const NodesT &no
     }
     return !so.end;
 }
+// One iteration of PathMatsIntegrator::Li's loop (src/pathMatsIntegrator.cpp:32-73): emission without MIS, roulette with
+// the throughput's largest component, BSDF sampling; no emitter sampling, no shadow ray.  The next ray keeps the camera
+// ray's maxt and starts at mint = 1e-4 (which switches the adaptive epsilon of the traversal on), as the reference does.
+template <bool EXT = false, typename StackT, typename NodesT>
+__device__ __forceinline__ bool path_bounce_mats(const DevScene &sc, const NodesT &nodes, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
+    Hit hit;
+    ctr.closest++;
+    if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+    Surface sf;
+    surface_from_hit<EXT>(sc, ps.ray, hit, sf, false);
+    const NoriHipShape &shp = sc.shapes[sf.shape];
+    if (shp.emitter >= 0) {
+        F3 wi = normalized(sf.p - ps.ray.o);
+        if (dot(sf.sh.n, wi) < 0) ps.li = ps.li + ps.t * f3(sc.emitters[shp.emitter].radiance);
+    }
+    const float m = fmaxf(ps.t.x, fmaxf(ps.t.y, ps.t.z));
+    const float successProb = m < 0.99f ? m : 0.99f;
+    if (rng.next1D() > successProb) return false;
+    ps.t = ps.t / successProb;
+    F3 wi_l = sf.sh.toLocal(-ps.ray.d);
+    F3 alb = f3(shp.albedo);
+    if (EXT && shp.albedo_tex) alb = tex_color(sc, sc.textures[shp.albedo_tex - 1], sf.uv);
+    F2 s2 = rng.next2D(); F2 s1 = rng.next2D();
+    F3 wo; bool is_delta, wo_valid;
+    F3 f = bsdf_sample(shp, alb, wi_l, s1, s2, wo, is_delta, wo_valid);
+    if (!wo_valid || is_zero(f)) return false;
+    ps.ray.d = normalized(sf.sh.toWorld(wo)); ps.ray.o = sf.p; ps.ray.mint = 1e-4f;
+    ps.t = ps.t * f;
+    return true;
+}
+
 template <bool EXT = false, typename StackT>
 __device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     GlobalNodes g; g.nodes = sc.nodes;

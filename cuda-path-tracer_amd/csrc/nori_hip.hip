@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_camera_rays(DevScene sc, const float *p
     rays[i] = o;
 }
 
-template <bool EXT>
+template <bool EXT, bool MATS = false>
 __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const int32_t *px, const int32_t *py, const uint64_t *states,
                                                     const uint64_t *seqs, const NoriHipRay *rays, float *rgb) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const
     else camera_ray(sc, f2(j.x * (float) sc.cam.width, j.y * (float) sc.cam.height), ray);      // src/ttest.cpp:171-172
     PathState ps; path_init(ps, ray);
     ScratchStack stk; Counters c = {0, 0, 0, 0};
-    while (path_bounce<EXT>(sc, ps, rng, stk, c)) { }
+    if (MATS) { GlobalNodes g; g.nodes = sc.nodes; while (path_bounce_mats<EXT>(sc, g, ps, rng, stk, c)) { } }
+    else while (path_bounce<EXT>(sc, ps, rng, stk, c)) { }
     rgb[3 * i] = ps.li.x; rgb[3 * i + 1] = ps.li.y; rgb[3 * i + 2] = ps.li.z;
 }
 
@@ -136,7 +137,7 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
 // fetch per trip), so it is built for several register budgets (waves per SIMD) and the host picks one.
 #define MEGA_THREADS 256
 #define MEGA_DEPTH 8
-template <bool EXT>
+template <bool EXT, bool MATS = false>
 __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob &job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     extern __shared__ float4 dyn_lds[];
     uint2 stack_spill[ND_STACK - MEGA_DEPTH];
@@ -183,7 +184,7 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
         }
         if (__ballot(alive) == 0ull) { if (exhausted && cursor >= end) break; else continue; }
         if (alive) {
-            if (!path_bounce<EXT>(sc, nodes, ps, rng, stk, ctr)) {
+            if (!(MATS ? path_bounce_mats<EXT>(sc, nodes, ps, rng, stk, ctr) : path_bounce<EXT>(sc, nodes, ps, rng, stk, ctr))) {
                 if (!film_put(sc, film, pixel_sample, px, py, ps.li)) n_invalid++;
                 alive = false;
             }
@@ -214,6 +215,9 @@ ND_RENDER_KERNEL(8)
 // scenes with images or subsurface shapes (DevScene::textures / NORI_HIP_BSDF_SUBSURFACE): one register budget
 __global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_ext(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     render_body<true>(sc, job, film, work_counter, stats, n_cached); }
+// NORI_HIP_INTEGRATOR_PATH_MATS (src/pathMatsIntegrator.cpp): every scene kind through one variant
+__global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_mats(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
+    render_body<true, true>(sc, job, film, work_counter, stats, n_cached); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Wavefront pipeline: the bounce loop of PathMisIntegrator::Li cut into stages that run as separate kernels over
@@ -772,6 +776,7 @@ struct NoriHipContext {
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
     NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
+    int integrator = NORI_HIP_INTEGRATOR_PATH_MIS;   // nori_hip_set_integrator
     lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
     uint32_t lbvh_leaf = 4;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF)
     float lbvh_big = 0.25f;           // records longer than this fraction of the scene get their own subtree (NORI_HIP_LBVH_BIG, 0 = off)
@@ -1019,6 +1024,13 @@ int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used
     return NORI_HIP_OK;
 }
 
+int nori_hip_set_integrator(NoriHipContext *ctx, int kind) {
+    CTXCHK(ctx);
+    if (kind != NORI_HIP_INTEGRATOR_PATH_MIS && kind != NORI_HIP_INTEGRATOR_PATH_MATS) return fail(NORI_HIP_EINVAL, "unknown integrator kind");
+    ctx->integrator = kind;
+    return NORI_HIP_OK;
+}
+
 int nori_hip_trace_device(NoriHipContext *ctx, const NoriHipRay *d_rays, size_t n, int any_hit, NoriHipHit *d_hits) {
     SCENECHK(ctx);
     if (n == 0) return NORI_HIP_OK;
@@ -1069,7 +1081,7 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     SCENECHK(ctx);
     if (n == 0) return NORI_HIP_OK;
     if (!states || !seqs || !rgb || ((px == nullptr) != (py == nullptr))) return fail(NORI_HIP_EINVAL, "null buffer");
-    if (ctx->sc.n_emitters == 0) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
+    if (ctx->sc.n_emitters == 0 && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
     int32_t *d_px = nullptr, *d_py = nullptr; uint64_t *d_st = nullptr, *d_sq = nullptr; NoriHipRay *d_rays = nullptr; float *d_rgb = nullptr;
     if (px) { HIPCHK(hipMalloc((void **) &d_px, n * 4)); HIPCHK(hipMemcpyAsync(d_px, px, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
     if (py) { HIPCHK(hipMalloc((void **) &d_py, n * 4)); HIPCHK(hipMemcpyAsync(d_py, py, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
@@ -1077,7 +1089,10 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     HIPCHK(hipMalloc((void **) &d_sq, n * 8)); HIPCHK(hipMemcpyAsync(d_sq, seqs, n * 8, hipMemcpyHostToDevice, ctx->stream));
     if (rays) { HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay))); HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream)); }
     HIPCHK(hipMalloc((void **) &d_rgb, n * 12));
-    if (ctx->ext)
+    if (ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)
+        hipLaunchKernelGGL((k_li_samples<true, true>), dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
+                           (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
+    else if (ctx->ext)
         hipLaunchKernelGGL(k_li_samples<true>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
                            (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
     else
@@ -1095,11 +1110,12 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     const int W = ctx->sc.cam.width, H = ctx->sc.cam.height;
     if (x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 >= x1 || y0 >= y1) return fail(NORI_HIP_EINVAL, "tile outside the image");
     if (spp_begin < 0 || spp_end <= spp_begin) return fail(NORI_HIP_EINVAL, "empty sample range");
-    if (ctx->sc.n_emitters == 0) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
+    if (ctx->sc.n_emitters == 0 && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
     RenderJob job; job.x0 = x0; job.y0 = y0; job.tw = x1 - x0; job.th = y1 - y0; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin;
     job.total = (unsigned long long) job.tw * job.th * job.nspp;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
-    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced)) {
+    const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS;
+    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced) || mats) {
         // single persistent kernel with per-lane path regeneration
         unsigned long long chunks = (job.total + MEGA_THREADS - 1) / MEGA_THREADS;
         const int W = ctx->mega_waves;
@@ -1111,7 +1127,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         const unsigned int n_cached = share > stack_bytes ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((share - stack_bytes) / 64)) : 0u;
         const size_t lds = stack_bytes + (size_t) n_cached * 64;
         void (*kern)(DevScene, RenderJob, float4 *, unsigned long long *, DevStats *, unsigned int) =
-            ctx->ext ? k_render_ext : W == 3 ? k_render_w3 : W == 4 ? k_render_w4 : W == 5 ? k_render_w5 : W == 6 ? k_render_w6 : k_render_w8;
+            mats ? k_render_mats : ctx->ext ? k_render_ext : W == 3 ? k_render_w3 : W == 4 ? k_render_w4 : W == 5 ? k_render_w5 : W == 6 ? k_render_w6 : k_render_w8;
         HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(MEGA_THREADS), lds, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats, n_cached);

@@ -20,7 +20,7 @@ static void hipCheck(int rc, const char *what) {
 /// default $NORI_HIP_BVH).
 class PathMisHip : public GpuIntegrator {
 public:
-    explicit PathMisHip(const PropertyList &props) {
+    explicit PathMisHip(const PropertyList &props, int kind = NORI_HIP_INTEGRATOR_PATH_MIS) : m_kind(kind) {
         const char *env = getenv("NORI_HIP_DEVICE");
         m_device = props.getInteger("device", env ? atoi(env) : 0);
         const char *benv = getenv("NORI_HIP_BVH");
@@ -32,8 +32,9 @@ public:
     ~PathMisHip() override { if (m_ctx) nori_hip_destroy(m_ctx); }
     void preprocess(const Scene *scene) override {
         flattenScene(scene, m_flat);
-        if (m_flat.desc.n_emitters == 0) throw NoriException("path_mis: the scene has no emitters");
+        if (m_flat.desc.n_emitters == 0 && m_kind == NORI_HIP_INTEGRATOR_PATH_MIS) throw NoriException("path_mis: the scene has no emitters");
         if (!m_ctx) hipCheck(nori_hip_create(m_device, &m_ctx), "nori_hip_create");
+        hipCheck(nori_hip_set_integrator(m_ctx, m_kind), "nori_hip_set_integrator");
         if (m_deviceBvh) hipCheck(nori_hip_upload_scene_build(m_ctx, &m_flat.desc), "nori_hip_upload_scene_build");
         else hipCheck(nori_hip_upload_scene(m_ctx, &m_flat.desc), "nori_hip_upload_scene");
     }
@@ -52,13 +53,18 @@ public:
     }
     NoriHipContext *context() override { return m_ctx; }
     const FlatScene &flat() const override { return m_flat; }
-    std::string toString() const override { return "PathMisIntegrator[backend=hip/gfx950]"; }
+    std::string toString() const override { return m_kind == NORI_HIP_INTEGRATOR_PATH_MATS ? "PathMatsIntegrator[backend=hip/gfx950]" : "PathMisIntegrator[backend=hip/gfx950]"; }
 private:
     void need() const { if (!m_ctx) throw NoriException("path_mis: preprocess() has not run"); }
-    int m_device = 0; bool m_deviceBvh = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
+    int m_kind; int m_device = 0; bool m_deviceBvh = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
 };
 static NoriObject *PathMisHip_create(const PropertyList &l) { return new PathMisHip(l); }
-static struct PathMisHip_reg { PathMisHip_reg() { NoriObjectFactory::registerClass("path_mis", PathMisHip_create); NoriObjectFactory::registerClass("path_mis_hip", PathMisHip_create); } } PathMisHip_reg_;
+// "path_mats" (src/pathMatsIntegrator.cpp:87): the same plugin with the other Li
+static NoriObject *PathMatsHip_create(const PropertyList &l) { return new PathMisHip(l, NORI_HIP_INTEGRATOR_PATH_MATS); }
+static struct PathMisHip_reg { PathMisHip_reg() {
+    NoriObjectFactory::registerClass("path_mis", PathMisHip_create); NoriObjectFactory::registerClass("path_mis_hip", PathMisHip_create);
+    NoriObjectFactory::registerClass("path_mats", PathMatsHip_create); NoriObjectFactory::registerClass("path_mats_hip", PathMatsHip_create);
+} } PathMisHip_reg_;
 
 /// The reference's test files also name integrators that are outside this build's scope.  They are
 /// accepted by the parser so those files load unmodified, and refuse to render.
@@ -74,7 +80,7 @@ private:
     std::string m_name;
 };
 static struct OutOfScope_reg { OutOfScope_reg() {
-    for (const char *n : {"path_mats", "direct_mis", "direct_ems", "direct_mats", "direct", "av", "normals", "photonmapper"})
+    for (const char *n : {"direct_mis", "direct_ems", "direct_mats", "direct", "av", "normals", "photonmapper"})
         NoriObjectFactory::registerClass(n, [n](const PropertyList &l) -> NoriObject * { return new OutOfScopeIntegrator(l, n); });
 } } OutOfScope_reg_;
 

@@ -34,6 +34,9 @@ extern "C" {
 enum { NORI_HIP_BSDF_DIFFUSE = 0, NORI_HIP_BSDF_MICROFACET = 1, NORI_HIP_BSDF_DIELECTRIC = 2, NORI_HIP_BSDF_MIRROR = 3,
        NORI_HIP_BSDF_SUBSURFACE = 4 };
 enum { NORI_HIP_SHAPE_MESH = 0, NORI_HIP_SHAPE_SPHERE = 1 };
+/* integrators (src/pathMisIntegrator.cpp — the hot path; src/pathMatsIntegrator.cpp — the other path integrator of the
+ * reference's own test files, BSDF sampling only) */
+enum { NORI_HIP_INTEGRATOR_PATH_MIS = 0, NORI_HIP_INTEGRATOR_PATH_MATS = 1 };
 /* image kinds and lookup modes (cuda/nori/imagetexture.cpp.cu, bumpMap.cpp.cu, normalMap.cpp.cu; src/imagetexture.cpp) */
 enum { NORI_HIP_TEX_COLOR = 0, NORI_HIP_TEX_BUMP = 1, NORI_HIP_TEX_NORMAL = 2 };
 enum { NORI_HIP_LOOKUP_NEAREST = 0, NORI_HIP_LOOKUP_BILINEAR = 1 };
@@ -186,6 +189,11 @@ int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *desc);
  * nori_hip_build_info: size of the node array, nodes in use, tree depth, device time of the build. */
 int nori_hip_upload_scene_build(NoriHipContext *ctx, const NoriHipSceneDesc *desc);
 int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used, uint32_t *depth, double *build_ms);
+
+/* Which Li the context's nori_hip_li_samples / nori_hip_render evaluate (default NORI_HIP_INTEGRATOR_PATH_MIS).  Replaces
+ * the choice of Integrator subclass by the scene file's <integrator type="..."> (NoriObjectFactory, src/parser.cpp).
+ * path_mats renders through the single-kernel pipeline. */
+int nori_hip_set_integrator(NoriHipContext *ctx, int kind);
 
 /* Closest-hit (any_hit = 0) or any-hit (any_hit != 0: hits[i].prim is 1 when occluded, NORI_HIP_MISS otherwise)
  * queries for n host rays.  Replaces Scene::rayIntersect -> BVH::rayIntersect (src/bvh.cpp:404-463) including

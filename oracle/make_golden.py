@@ -140,7 +140,7 @@ def test_scene_fixtures():
         xml = os.path.join(ROOT, "scenes", "tests", fname)
         ot = O.OracleScene(xml, is_test=True)
         for i, px in enumerate(split_test_scenes(xml)):
-            if not ot.test_meta(i)["path_mis"]:
+            if ot.test_meta(i)["integrator"] is None:
                 continue
             with quiet():
                 r = R.RefScene(px, os.path.dirname(xml))
@@ -216,7 +216,7 @@ def ttest_fixture():
         means = []
         for i, px in enumerate(parts):
             meta = ot.test_meta(i)
-            if not meta["path_mis"]:
+            if meta["integrator"] is None:
                 means.append((np.nan, np.nan, meta["reference"]))
                 continue
             with quiet():
@@ -246,7 +246,9 @@ def main():
               # 105 k triangles, depth-26 tree, a 960-triangle mesh emitter (CDF search) and an emitter of zero radiance
               ("dragon", S + "/proj/dragon-diffuse.xml", 64, 48, 2048, 5),
               # two subsurface shapes (sphere mesh dmfp 0.1, cube dmfp 0.01): probe rays with the shape mask, sampleDx retries
-              ("cbox_subsurface", S + "/proj/cbox_subsurface.xml", 64, 48, 4096, 6)]
+              ("cbox_subsurface", S + "/proj/cbox_subsurface.xml", 64, 48, 4096, 6),
+              # the other path integrator of the reference's tests (src/pathMatsIntegrator.cpp): BSDF sampling only
+              ("cbox_path_mats", S + "/cbox/cbox_path_mats.xml", 64, 64, 2048, 7)]
     for sc in scenes:
         if not only or sc[0] in only:
             scene_fixture(*sc)

@@ -48,8 +48,10 @@ int orc_test_sample_count(void *hp) { return ((Handle *) hp)->suite.sample_count
 float orc_test_significance(void *hp) { return ((Handle *) hp)->suite.significance; }
 float orc_test_reference(void *hp, int i) { return ((Handle *) hp)->suite.references[i]; }
 int orc_test_is_path_mis(void *hp, int i) { return ((Handle *) hp)->suite.scenes[i].integrator == "path_mis"; }
+// 0 path_mis, 1 path_mats, -1 anything else (not restated)
+int orc_test_integrator(void *hp, int i) { const std::string &n = ((Handle *) hp)->suite.scenes[i].integrator; return n == "path_mis" ? 0 : n == "path_mats" ? 1 : -1; }
 // Runs scenes [0, n) in order with ONE default-seeded sampler carried across scenes, as src/ttest.cpp:152-156 does;
-// scenes whose integrator is not path_mis still consume the stream through path_mis (documented divergence).
+// every scene through the integrator it names (path_mis or path_mats).
 void orc_test_run(void *hp, int only_path_mis, double *means, double *variances) {
     Handle *h = (Handle *) hp; Sampler smp;
     for (size_t i = 0; i < h->suite.scenes.size(); ++i) {
@@ -182,7 +184,7 @@ void orc_li_samples(void *hp, int si, int n, const int *px, const int *py, const
         Sampler s; s.rng.seed(states[i], seqs[i]);
         V2 j = s.next2D(); V2 ps = mk2((float) px[i] + j.x, (float) py[i] + j.y); (void) s.next2D();
         Ray ray; sc->camera.sample_ray(ray, ps);
-        V3 v = path_mis_li(*ac, s, ray);
+        V3 v = scene_li(*ac, s, ray);
         rgb[3 * i] = v.x; rgb[3 * i + 1] = v.y; rgb[3 * i + 2] = v.z;
         if (pixel_samples) { pixel_samples[2 * i] = ps.x; pixel_samples[2 * i + 1] = ps.y; }
     }
@@ -254,7 +256,7 @@ void orc_li_rays(void *hp, int si, int n, const float *rays, const uint64_t *sta
         Sampler s; s.rng.seed(states[i], seqs[i]); (void) s.next2D(); (void) s.next2D();
         const float *q = rays + 8 * (size_t) i;
         Ray r; r.o = mk3(q[0], q[1], q[2]); r.mint = q[3]; r.d = mk3(q[4], q[5], q[6]); r.maxt = q[7]; r.update();
-        V3 v = path_mis_li(*ac, s, r);
+        V3 v = scene_li(*ac, s, r);
         rgb[3 * i] = v.x; rgb[3 * i + 1] = v.y; rgb[3 * i + 2] = v.z;
     }
 }

@@ -569,6 +569,44 @@ inline V3 path_mis_li(const Accel &acc, Sampler &smp, const Ray &_ray, PathStats
     return li;
 }
 
+// ---- PathMatsIntegrator::Li (src/pathMatsIntegrator.cpp:19-77): BSDF sampling only --------------------------------
+// Same remark as above on zero BSDF weights.  Note what the reference leaves as it is: the next ray keeps the camera
+// ray's maxt (only o, d and mint are reassigned, :66-69) and mint = 1e-4 = Epsilon switches the adaptive ray epsilon of
+// BVH::rayIntersect on (src/bvh.cpp:411-412); the survival probability is min(0.99, max(t)) (:46).
+inline V3 path_mats_li(const Accel &acc, Sampler &smp, const Ray &_ray, PathStats *st = nullptr) {
+    const Scene &sc = *acc.scene;
+    Ray ray = _ray;
+    V3 li = mk3(0.f), t = mk3(1.0f);
+    while (true) {
+        Intersection its;
+        if (st) st->closest++;
+        if (!acc.ray_intersect(ray, its, false, -1, st ? &st->tc : nullptr)) break;
+        const Shape &mesh = sc.shapes[its.shape];
+        if (mesh.emitter >= 0) {
+            EmitterRec q; q.ref = ray.o; q.p = its.p; q.n = its.sh.n; q.wi = normalized(its.p - ray.o);
+            li = li + t * emitter_eval(sc.emitters[mesh.emitter], q);
+        }
+        float successProb = std::min(0.99f, maxcoeff(t));
+        if (smp.next1D() > successProb) break;
+        t = t / successProb;
+        if (st) st->bounces++;
+        const Bsdf &bsdf = mesh.bsdf;
+        BsdfRec br; br.wi = its.sh.toLocal(-ray.d); br.uv = its.uv;
+        br.albedo = bsdf.albedo_tex >= 0 ? image_color(sc.images[bsdf.albedo_tex], its.uv) : bsdf.albedo;
+        V2 s2 = smp.next2D(), s1 = smp.next2D();              // right-to-left argument evaluation, as in path_mis
+        V3 f = bsdf_sample(bsdf, br, s1, s2);
+        if (!br.wo_valid || is_zero(f)) break;
+        ray.d = normalized(its.sh.toWorld(br.wo)); ray.o = its.p; ray.mint = 1e-4; ray.update();
+        t = t * f;
+    }
+    return li;
+}
+// the integrator a scene names
+inline V3 scene_li(const Accel &acc, Sampler &smp, const Ray &ray, PathStats *st = nullptr) {
+    if (acc.scene->integrator == "path_mats") return path_mats_li(acc, smp, ray, st);
+    return path_mis_li(acc, smp, ray, st);
+}
+
 // ---- film (src/block.cpp:38-140) ------------------------------------------------------------------------
 struct Film {
     int w = 0, h = 0, border = 0;
@@ -649,7 +687,7 @@ inline void render(const Accel &acc, Film &film, int spp_begin, int spp_end, int
                     V2 pixelSample = mk2((float) (x + ox) + j.x, (float) (y + oy) + j.y);
                     (void) s->next2D();                                   // apertureSample (src/render.cpp:86)
                     Ray ray; cam.sample_ray(ray, pixelSample);
-                    V3 value = path_mis_li(acc, *s, ray, &ps);
+                    V3 value = scene_li(acc, *s, ray, &ps);
                     out.emplace_back(pixelSample, value);
                 }
                 std::lock_guard<std::mutex> lk(film_mutex);
@@ -674,7 +712,7 @@ inline void ttest_scene(const Accel &acc, Sampler &smp, int n, double &mean, dou
         V2 pixelSample = mk2(u.x * (float) cam.width, u.y * (float) cam.height);
         (void) smp.next2D();
         Ray ray; cam.sample_ray(ray, pixelSample);
-        V3 value = path_mis_li(acc, smp, ray);
+        V3 value = scene_li(acc, smp, ray);
         double result = (double) luminance(value);
         double delta = result - mean;
         mean += delta / (double) (k + 1);

@@ -17,6 +17,7 @@ SCENE_XML = {
     "table_microfacet": "table/table_path_mis_microfacet.xml",
     "dragon": "proj/dragon-diffuse.xml",
     "cbox_subsurface": "proj/cbox_subsurface.xml",       # subsurface shapes: probe rays, masked traversal (EXT kernels)
+    "cbox_path_mats": "cbox/cbox_path_mats.xml",         # path_mats integrator (k_render_mats)
 }
 # scenes with images (no reference fixtures: the reference needs OpenCV to load them; the oracle's restatement is the checker)
 IMAGE_XML = {"texture_bump": "proj/textureAndBump.xml", "normal_map": "proj/normal.xml"}
@@ -46,11 +47,20 @@ def test_hits_bit_exact_against_reference_fixtures(name, loaded):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     hs, ctx = loaded(name, int(g["width"]), int(g["height"]))
     hits, full = ctx.trace(g["rays"], full=True)
-    assert np.array_equal(hits_as_u32(hits), g["hits"])                       # primary hits: prim id, t, uv bit-exact
-    assert np.array_equal(full[:, 0:5], g["full"][:, 0:5])                    # p, uv
+    # analytic spheres (src/sphere.cpp:131-138) take their uv from acos / atan2, where the device's libm and glibc differ in
+    # the last place: on those hits uv (both in [0, 1]) may be off by 5e-7; everything else is bit-exact everywhere
+    sphere_shapes = np.nonzero(hs.tables()["shapes"]["type"] == 1)[0]
+    def same_hits(h, ref, shape):
+        on_sphere = np.isin(shape, sphere_shapes) & (ref[:, 0] != NH.MISS)
+        assert np.array_equal(h[:, 0:2], ref[:, 0:2])                         # prim id, t
+        assert np.array_equal(h[~on_sphere, 2:4], ref[~on_sphere, 2:4])       # uv
+        assert np.abs(h[on_sphere, 2:4].copy().view(np.float32) - ref[on_sphere, 2:4].copy().view(np.float32)).max(initial=0) <= 5e-7
+        return on_sphere
+    sp = same_hits(hits_as_u32(hits), g["hits"], g["full"][:, 11].astype(np.int64))
+    assert np.array_equal(full[:, 0:3], g["full"][:, 0:3]) and np.array_equal(full[~sp, 3:5], g["full"][~sp, 3:5])   # p, uv
     assert np.array_equal(full[:, 5:12], g["full"][:, 5:12])                  # normals, shape
     bh = ctx.trace(g["bounce_rays"])
-    assert np.array_equal(hits_as_u32(bh), g["bounce_hits"])
+    same_hits(hits_as_u32(bh), g["bounce_hits"], g["bounce_full"][:, 11].astype(np.int64))
     sh = ctx.trace(g["shadow_rays"], any_hit=True)
     assert np.array_equal(sh["prim"], g["shadow_hits"])
 

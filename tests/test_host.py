@@ -134,7 +134,7 @@ def test_texture_plugins_report_errors_like_the_reference(tmp_path):
 def test_single_leaf_scene_and_test_files_load():
     ht = NH.HostScene(os.path.join(SCENES, "tests", "test-direct.xml"))
     assert ht.is_test and ht.scene_count == 10
-    assert not ht.test_meta(0)["path_mis"] and ht.test_meta(5)["path_mis"]
+    assert ht.test_meta(0)["path_mis"] and ht.test_meta(5)["path_mis"]          # rows 0-4 path_mats, 5-9 path_mis: both have the GPU backend
     assert abs(ht.test_meta(5)["reference"] - 0.0898394) < 1e-7
     T = ht.tables(5)
     assert T["desc"].root == 0x80000000 and len(T["nodes"]) == 0 and len(T["prims"]) == 3

@@ -16,6 +16,7 @@ SCENE_XML = {
     "table_microfacet": "table/table_path_mis_microfacet.xml",
     "dragon": "proj/dragon-diffuse.xml",
     "cbox_subsurface": "proj/cbox_subsurface.xml",       # subsurface shapes: probe rays with the shape mask (src/subsurface.cpp)
+    "cbox_path_mats": "cbox/cbox_path_mats.xml",         # the other path integrator (src/pathMatsIntegrator.cpp)
 }
 
 
@@ -164,7 +165,7 @@ def test_oracle_passes_the_references_own_ttests():
         n_tests = o.test_count()
         for i in range(n_tests):
             m = o.test_meta(i)
-            if not m["path_mis"]:
+            if m["integrator"] is None:
                 continue
             mean, var = o.test_run_one(i, i, 0, 100000 if "direct" in fname else 30000)
             n = 100000 if "direct" in fname else 30000
