@@ -169,5 +169,12 @@ int nori_host_test_run(NoriHostScene *h, int scene, double *out) {
 int nori_host_render_file(const char *xml_path, char *out_path, size_t out_len) {
     GUARD( std::string o = renderScene(xml_path); if (out_path && out_len) { strncpy(out_path, o.c_str(), out_len - 1); out_path[out_len - 1] = 0; } return 0; )
 }
+int nori_host_write_image(const char *path, const float *rgb, int w, int h) {
+    GUARD(
+        std::string p(path); std::vector<float> v(rgb, rgb + (size_t) w * h * 3);
+        if (p.size() > 4 && p.substr(p.size() - 4) == ".png") writePNG(p, v, w, h); else writePFM(p, v, w, h);
+        return 0;
+    )
+}
 
 } // extern "C"

@@ -176,6 +176,42 @@ void writePFM(const std::string &path, const std::vector<float> &rgb, int w, int
     for (int y = h - 1; y >= 0; --y) f.write(reinterpret_cast<const char *>(&rgb[(size_t) y * w * 3]), (std::streamsize) w * 3 * 4);
 }
 
+// 8-bit sRGB PNG (what Bitmap::savePNG writes next to the EXR, src/bitmap.cpp:109-123: toSRGB, clamp, * 255), encoded with
+// stored (uncompressed) deflate blocks so that no compression library is needed
+void writePNG(const std::string &path, const std::vector<float> &rgb, int w, int h) {
+    if (w <= 0 || h <= 0 || rgb.size() < (size_t) w * h * 3) throw NoriException("writePNG: bad image size");
+    static uint32_t crcTable[256]; static bool crcInit = false;
+    if (!crcInit) { for (uint32_t n = 0; n < 256; ++n) { uint32_t c = n; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; crcTable[n] = c; } crcInit = true; }
+    auto crc = [&](const std::vector<uint8_t> &d, size_t from) { uint32_t c = 0xffffffffu; for (size_t i = from; i < d.size(); ++i) c = crcTable[(c ^ d[i]) & 0xff] ^ (c >> 8); return c ^ 0xffffffffu; };
+    auto be32 = [](std::vector<uint8_t> &d, uint32_t v) { d.push_back((uint8_t) (v >> 24)); d.push_back((uint8_t) (v >> 16)); d.push_back((uint8_t) (v >> 8)); d.push_back((uint8_t) v); };
+    auto toSRGB = [](float v) { return v <= 0.0031308f ? 12.92f * v : (1.0f + 0.055f) * std::pow(v, 1.0f / 2.4f) - 0.055f; };      // src/common.cpp:190-206
+    std::vector<uint8_t> raw; raw.reserve((size_t) h * (3 * w + 1));
+    for (int y = 0; y < h; ++y) {
+        raw.push_back(0);                                                      // filter type "none"
+        for (int x = 0; x < 3 * w; ++x) { float v = toSRGB(rgb[(size_t) y * 3 * w + x]) * 255.f; raw.push_back((uint8_t) (v != v || v < 0.f ? 0.f : v > 255.f ? 255.f : v)); }
+    }
+    std::vector<uint8_t> z; z.push_back(0x78); z.push_back(0x01);              // zlib header, then stored blocks of at most 65535 bytes
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size(); off += 65535) {
+        size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t) n); z.push_back((uint8_t) (n >> 8)); z.push_back((uint8_t) ~n); z.push_back((uint8_t) (~n >> 8));
+        for (size_t i = 0; i < n; ++i) { uint8_t c = raw[off + i]; z.push_back(c); a = (a + c) % 65521u; b = (b + a) % 65521u; }
+    }
+    be32(z, (b << 16) | a);                                                    // adler32
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    auto chunk = [&](const char *type, const std::vector<uint8_t> &data) {
+        be32(out, (uint32_t) data.size()); size_t from = out.size();
+        out.insert(out.end(), type, type + 4); out.insert(out.end(), data.begin(), data.end());
+        be32(out, crc(out, from));
+    };
+    std::vector<uint8_t> ihdr; be32(ihdr, (uint32_t) w); be32(ihdr, (uint32_t) h); ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk("IHDR", ihdr); chunk("IDAT", z); chunk("IEND", {});
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw NoriException::format("Unable to write \"%s\"", path.c_str());
+    f.write(reinterpret_cast<const char *>(out.data()), (std::streamsize) out.size());
+}
+
 std::string renderScene(const std::string &filename, int passSize) {
     size_t slash = filename.find_last_of('/');
     getFileResolver()->prepend(slash == std::string::npos ? std::string(".") : filename.substr(0, slash));
@@ -189,6 +225,7 @@ std::string renderScene(const std::string &filename, int passSize) {
     std::vector<float> rgb; scene->getIntegrator()->readBitmap(rgb);
     std::string out = filename; size_t dot = out.find_last_of('.'); if (dot != std::string::npos) out.erase(dot); out += ".pfm";
     writePFM(out, rgb, scene->getCamera()->getWidth(), scene->getCamera()->getHeight());
+    writePNG(out.substr(0, out.size() - 4) + ".png", rgb, scene->getCamera()->getWidth(), scene->getCamera()->getHeight());
     return out;
 }
 

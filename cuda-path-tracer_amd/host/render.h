@@ -40,6 +40,7 @@ private:
 /// Loads, renders and writes <scene>.pfm next to the XML; returns the output path (src/render.cpp:103-214)
 std::string renderScene(const std::string &filename, int passSize = 0);
 void writePFM(const std::string &path, const std::vector<float> &rgb, int w, int h);
+void writePNG(const std::string &path, const std::vector<float> &rgb, int w, int h);
 void arrayMeshSet(Mesh *m, const std::string &name, const float *V, size_t nV, const uint32_t *F, size_t nF, const float *N, const float *UV);
 
 } // namespace nori

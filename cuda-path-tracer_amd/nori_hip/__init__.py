@@ -129,6 +129,7 @@ def host_lib():
         L.nori_host_test_meta.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(i32)]
         L.nori_host_test_run.argtypes = [vp, i32, vp]
         L.nori_host_render_file.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.nori_host_write_image.argtypes = [C.c_char_p, vp, i32, i32]
         _host = L
     return _host
 
@@ -377,6 +378,12 @@ class SceneBuilder:
     def finish(self, spp=1, build_threads=0):
         _ochk(self.L.nori_host_scene_end(self.h, spp, build_threads))
         return HostScene(handle=self.h.value)
+
+
+def write_image(path, rgb):
+    """linear rgb (H x W x 3) to "*.png" (8-bit sRGB) or PFM"""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    _ochk(host_lib().nori_host_write_image(os.fspath(path).encode(), _vp(rgb), rgb.shape[1], rgb.shape[0]))
 
 
 def render_file(xml):

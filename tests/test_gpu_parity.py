@@ -151,6 +151,14 @@ def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
             ctx.render(0, 8, tile=(0, y0, W, y1))
     bands = ctx.read_film()
     assert np.array_equal(bands[:, :, 3], whole[:, :, 3]) and np.allclose(bands, whole, rtol=1e-4, atol=1e-5)
+    # checkpoint / resume: the film is sums + weights, so a saved film plus the remaining sample indices is the same render
+    ctx.clear_film(); ctx.render(0, 5)
+    saved = ctx.read_film()
+    ctx.clear_film()
+    assert not ctx.read_film().any()
+    ctx.write_film(saved); ctx.render(5, 8)
+    resumed = ctx.read_film()
+    assert np.array_equal(resumed[:, :, 3], whole[:, :, 3]) and np.allclose(resumed, whole, rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["cbox_mirror_microfacet", "table", "dragon", "cbox_subsurface", "texture_bump"])

@@ -223,3 +223,24 @@ def test_binary_mesh_cache_round_trip(tmp_path):
         n0, i0 = plain.bvh32()
         n1, i1 = hs.bvh32()
         assert np.array_equal(n0, n1) and np.array_equal(i0, i1)
+
+
+def test_png_and_pfm_writers(tmp_path):
+    """the headless driver's outputs: PFM (raw floats) and the 8-bit sRGB PNG of Bitmap::savePNG (src/bitmap.cpp:109-123)"""
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    img = (rng.random((37, 301, 3)) ** 2 * 1.2).astype(np.float32)          # some values above 1: clamped; 301*3+1 bytes per row
+    img[0, 0] = [np.nan, -1.0, 0.5]
+    NH.write_image(tmp_path / "a.png", img)
+    got = np.asarray(Image.open(tmp_path / "a.png").convert("RGB"))
+    v = np.where(img <= 0.0031308, 12.92 * img, 1.055 * np.power(np.maximum(img, 0), 1 / 2.4) - 0.055) * 255
+    want = np.where(np.isnan(v) | (v < 0), 0, np.minimum(v, 255)).astype(np.uint8)
+    assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    big = np.tile(img, (8, 1, 1))                                            # > 65535 bytes: several stored deflate blocks
+    NH.write_image(tmp_path / "b.png", big)
+    assert np.asarray(Image.open(tmp_path / "b.png")).shape == big.shape
+    NH.write_image(tmp_path / "a.pfm", img)
+    raw = (tmp_path / "a.pfm").read_bytes()
+    assert raw.startswith(b"PF\n301 37\n-1.0\n")
+    back = np.frombuffer(raw[len(b"PF\n301 37\n-1.0\n"):], np.float32).reshape(37, 301, 3)[::-1]
+    assert np.array_equal(back, img, equal_nan=True)
