@@ -247,6 +247,8 @@ def main():
               ("dragon", S + "/proj/dragon-diffuse.xml", 64, 48, 2048, 5),
               # two subsurface shapes (sphere mesh dmfp 0.1, cube dmfp 0.01): probe rays with the shape mask, sampleDx retries
               ("cbox_subsurface", S + "/proj/cbox_subsurface.xml", 64, 48, 4096, 6),
+              # subsurface on the 100 k-triangle dragon (masked probes through a depth-26 tree)
+              ("dragon_ss", S + "/proj/dragon-ss.xml", 64, 48, 2048, 8),
               # the other path integrator of the reference's tests (src/pathMatsIntegrator.cpp): BSDF sampling only
               ("cbox_path_mats", S + "/cbox/cbox_path_mats.xml", 64, 64, 2048, 7)]
     for sc in scenes:

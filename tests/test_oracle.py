@@ -16,6 +16,7 @@ SCENE_XML = {
     "table_microfacet": "table/table_path_mis_microfacet.xml",
     "dragon": "proj/dragon-diffuse.xml",
     "cbox_subsurface": "proj/cbox_subsurface.xml",       # subsurface shapes: probe rays with the shape mask (src/subsurface.cpp)
+    "dragon_ss": "proj/dragon-ss.xml",                   # subsurface dragon: masked probes through the deep tree
     "cbox_path_mats": "cbox/cbox_path_mats.xml",         # the other path integrator (src/pathMatsIntegrator.cpp)
 }
 
