@@ -93,19 +93,34 @@ def film_tensor(ctx, torch):
 
 
 def cpu_baseline(w, args):
-    """The oracle (CPU restatement, pinned bit-for-bit against the reference's sources) timed on this host."""
+    """The oracle (CPU restatement, pinned bit-for-bit against the reference's sources) timed on this host: all threads the
+    box gives us on a bounded sample of the workload, one thread on a smaller one, BVH build apart."""
     import oracle_lib as O
     threads = min(16, os.cpu_count() or 1)
     if w["xml"] is None:
         return None
     spp = args.cpu_spp
+    t0 = time.time()
     o = O.OracleScene(os.path.join(ROOT, w["xml"]), w["width"], w["height"], spp)
+    load_s = time.time() - t0                                   # OBJ parse + SAH BVH build (one thread, the reference's order)
     sec, st = o.render(0, spp, mode=0, threads=threads)
     n = w["width"] * w["height"] * spp
+    spp1 = max(1, spp // 16)
+    sec1, _ = o.render(0, spp1, mode=0, threads=1)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(n / sec / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": "%dx%d, %d spp of the same scene (%.1f s), reference block-stream mode; the unmodified reference measured 1.62 Msamples/s on 8 threads in the survey container" % (
                 w["width"], w["height"], spp, sec),
-            "mrays_per_s": round((st["closest"] + st["shadow"]) / sec / 1e6, 3)}
+            "mrays_per_s": round((st["closest"] + st["shadow"]) / sec / 1e6, 3),
+            "single_thread": {"value": round(w["width"] * w["height"] * spp1 / sec1 / 1e6, 4), "sample": "%d spp (%.1f s)" % (spp1, sec1)},
+            "cpu_model": model, "host_cpus": os.cpu_count(), "scene_load_and_bvh_build_s": round(load_s, 3)}
 
 
 def main():
