@@ -172,7 +172,8 @@ int nori_host_render_file(const char *xml_path, char *out_path, size_t out_len) 
 int nori_host_write_image(const char *path, const float *rgb, int w, int h) {
     GUARD(
         std::string p(path); std::vector<float> v(rgb, rgb + (size_t) w * h * 3);
-        if (p.size() > 4 && p.substr(p.size() - 4) == ".png") writePNG(p, v, w, h); else writePFM(p, v, w, h);
+        const std::string ext = p.size() > 4 ? p.substr(p.size() - 4) : std::string();
+        if (ext == ".png") writePNG(p, v, w, h); else if (ext == ".exr") writeEXR(p, v, w, h); else writePFM(p, v, w, h);
         return 0;
     )
 }

@@ -212,6 +212,42 @@ void writePNG(const std::string &path, const std::vector<float> &rgb, int w, int
     f.write(reinterpret_cast<const char *>(out.data()), (std::streamsize) out.size());
 }
 
+// OpenEXR, the reference's native output (Bitmap::save, src/bitmap.cpp:82-107: channels R, G, B as 32-bit floats): a
+// single-part scanline file without compression, written directly (the format is a header of named attributes, a table of
+// line offsets, and per line the channels in alphabetical order)
+void writeEXR(const std::string &path, const std::vector<float> &rgb, int w, int h) {
+    if (w <= 0 || h <= 0 || rgb.size() < (size_t) w * h * 3) throw NoriException("writeEXR: bad image size");
+    std::vector<uint8_t> o;
+    auto u8 = [&](uint8_t v) { o.push_back(v); };
+    auto i32 = [&](int32_t v) { for (int k = 0; k < 4; ++k) o.push_back((uint8_t) ((uint32_t) v >> (8 * k))); };
+    auto u64 = [&](uint64_t v) { for (int k = 0; k < 8; ++k) o.push_back((uint8_t) (v >> (8 * k))); };
+    auto f32 = [&](float v) { uint32_t u; std::memcpy(&u, &v, 4); i32((int32_t) u); };
+    auto str = [&](const char *s) { while (*s) o.push_back((uint8_t) *s++); o.push_back(0); };
+    auto attr = [&](const char *name, const char *type, int32_t size) { str(name); str(type); i32(size); };
+    i32(20000630); i32(2);                                                     // magic, version 2, no flags
+    attr("channels", "chlist", 3 * 18 + 1);
+    for (const char *c : {"B", "G", "R"}) { str(c); i32(2 /* FLOAT */); u8(0); u8(0); u8(0); u8(0); i32(1); i32(1); }
+    u8(0);
+    attr("compression", "compression", 1); u8(0);                              // NO_COMPRESSION
+    attr("dataWindow", "box2i", 16); i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attr("displayWindow", "box2i", 16); i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attr("lineOrder", "lineOrder", 1); u8(0);                                  // INCREASING_Y
+    attr("pixelAspectRatio", "float", 4); f32(1.0f);
+    attr("screenWindowCenter", "v2f", 8); f32(0.0f); f32(0.0f);
+    attr("screenWindowWidth", "float", 4); f32(1.0f);
+    u8(0);                                                                     // end of header
+    const uint64_t lineBytes = 8 + (uint64_t) w * 12, table = o.size();
+    for (int y = 0; y < h; ++y) u64(table + (uint64_t) h * 8 + (uint64_t) y * lineBytes);
+    o.reserve(o.size() + (size_t) h * lineBytes);
+    for (int y = 0; y < h; ++y) {
+        i32(y); i32(w * 12);
+        for (int c = 2; c >= 0; --c) for (int x = 0; x < w; ++x) f32(rgb[((size_t) y * w + x) * 3 + c]);
+    }
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw NoriException::format("Unable to write \"%s\"", path.c_str());
+    f.write(reinterpret_cast<const char *>(o.data()), (std::streamsize) o.size());
+}
+
 std::string renderScene(const std::string &filename, int passSize) {
     size_t slash = filename.find_last_of('/');
     getFileResolver()->prepend(slash == std::string::npos ? std::string(".") : filename.substr(0, slash));
@@ -226,6 +262,7 @@ std::string renderScene(const std::string &filename, int passSize) {
     std::string out = filename; size_t dot = out.find_last_of('.'); if (dot != std::string::npos) out.erase(dot); out += ".pfm";
     writePFM(out, rgb, scene->getCamera()->getWidth(), scene->getCamera()->getHeight());
     writePNG(out.substr(0, out.size() - 4) + ".png", rgb, scene->getCamera()->getWidth(), scene->getCamera()->getHeight());
+    writeEXR(out.substr(0, out.size() - 4) + ".exr", rgb, scene->getCamera()->getWidth(), scene->getCamera()->getHeight());
     return out;
 }
 

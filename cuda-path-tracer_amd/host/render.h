@@ -41,6 +41,7 @@ private:
 std::string renderScene(const std::string &filename, int passSize = 0);
 void writePFM(const std::string &path, const std::vector<float> &rgb, int w, int h);
 void writePNG(const std::string &path, const std::vector<float> &rgb, int w, int h);
+void writeEXR(const std::string &path, const std::vector<float> &rgb, int w, int h);
 void arrayMeshSet(Mesh *m, const std::string &name, const float *V, size_t nV, const uint32_t *F, size_t nF, const float *N, const float *UV);
 
 } // namespace nori

@@ -51,10 +51,11 @@ int nori_host_render(NoriHostScene *h, int scene, int spp_begin, int spp_end);
 int nori_host_test_meta(NoriHostScene *h, int scene, float *reference, int *sample_count, float *significance, int *is_path_mis);
 int nori_host_test_run(NoriHostScene *h, int scene, double *out);
 
-/* h x w x 3 linear rgb floats to a file: "*.png" = 8-bit sRGB PNG (Bitmap::savePNG, src/bitmap.cpp:109-123), anything else = PFM */
+/* h x w x 3 linear rgb floats to a file: "*.exr" = OpenEXR, float R G B, uncompressed scanlines (Bitmap::save, src/bitmap.cpp:82-107),
+ * "*.png" = 8-bit sRGB PNG (Bitmap::savePNG, :109-123), anything else = PFM */
 int nori_host_write_image(const char *path, const float *rgb, int w, int h);
 
-/* renderScene (src/render.cpp:103): XML in, <scene>.pfm and <scene>.png out; out_path receives the .pfm file name */
+/* renderScene (src/render.cpp:103): XML in, <scene>.pfm, <scene>.exr and <scene>.png out; out_path receives the .pfm file name */
 int nori_host_render_file(const char *xml_path, char *out_path, size_t out_len);
 
 #ifdef __cplusplus

@@ -244,3 +244,44 @@ def test_png_and_pfm_writers(tmp_path):
     assert raw.startswith(b"PF\n301 37\n-1.0\n")
     back = np.frombuffer(raw[len(b"PF\n301 37\n-1.0\n"):], np.float32).reshape(37, 301, 3)[::-1]
     assert np.array_equal(back, img, equal_nan=True)
+
+
+def test_exr_writer_follows_the_openexr_layout(tmp_path):
+    """the reference's native output (src/bitmap.cpp:82-107).  Read back here by walking the file as the OpenEXR file-layout
+    document describes it: magic, version, attributes, line-offset table, scanline blocks with channels in alphabetical order"""
+    import struct
+    rng = np.random.default_rng(6)
+    img = rng.random((19, 33, 3)).astype(np.float32) * 4
+    NH.write_image(tmp_path / "a.exr", img)
+    b = (tmp_path / "a.exr").read_bytes()
+    assert struct.unpack_from("<iI", b, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    def cstr(p):
+        e = b.index(b"\0", p)
+        return b[p:e].decode(), e + 1
+    while b[pos] != 0:
+        name, pos = cstr(pos)
+        typ, pos = cstr(pos)
+        size, = struct.unpack_from("<i", b, pos)
+        attrs[name] = (typ, b[pos + 4:pos + 4 + size])
+        pos += 4 + size
+    pos += 1
+    assert {"channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth"} <= set(attrs)
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, 32, 18)
+    ch, p, names = attrs["channels"][1], 0, []
+    while ch[p] != 0:
+        e = ch.index(b"\0", p)
+        names.append(ch[p:e].decode())
+        assert struct.unpack_from("<iB3xii", ch, e + 1) == (2, 0, 1, 1)      # FLOAT, sampling 1 x 1
+        p = e + 1 + 16
+    assert names == ["B", "G", "R"]
+    offsets = struct.unpack_from("<19Q", b, pos)
+    out = np.zeros_like(img)
+    for y, off in enumerate(offsets):
+        yy, nbytes = struct.unpack_from("<ii", b, off)
+        assert (yy, nbytes) == (y, 33 * 12)
+        planes = np.frombuffer(b, np.float32, 33 * 3, off + 8).reshape(3, 33)
+        out[y] = planes[::-1].T                                               # B, G, R planes -> r, g, b
+    assert off + 8 + 33 * 12 == len(b)
+    assert np.array_equal(out, img)
