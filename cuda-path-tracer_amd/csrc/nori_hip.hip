@@ -34,6 +34,18 @@ thread_local std::string g_err;
 int fail(int code, const std::string &m) { g_err = m; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(NORI_HIP_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
+// device scratch of one API call: released on every return path, error returns included
+struct DevBufs {
+    std::vector<void *> owned;
+    ~DevBufs() { for (void *q : owned) (void) hipFree(q); }
+    template <typename T> hipError_t get(T *&out, size_t bytes) {
+        void *q = nullptr; hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+        if (e == hipSuccess) owned.push_back(q);
+        out = static_cast<T *>(q);
+        return e;
+    }
+};
+
 // Atomics that hit the same 256-byte line are served one after the other by the memory side, about 11 ns each on
 // MI355X (scratch/atombench.hip), whatever their address within the line; distinct lines proceed in parallel.
 // Every counter the kernels bump therefore sits on a line of its own, and the hot ones are striped over ND_STRIPES
@@ -1045,10 +1057,10 @@ int nori_hip_trace(NoriHipContext *ctx, const NoriHipRay *rays, size_t n, int an
     SCENECHK(ctx);
     if (n == 0) return NORI_HIP_OK;
     if (!rays || !hits) return fail(NORI_HIP_EINVAL, "null ray/hit buffer");
-    NoriHipRay *d_rays = nullptr; NoriHipHit *d_hits = nullptr; float *d_full = nullptr;
-    HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay)));
-    HIPCHK(hipMalloc((void **) &d_hits, n * sizeof(NoriHipHit)));
-    if (full) HIPCHK(hipMalloc((void **) &d_full, n * 16 * sizeof(float)));
+    DevBufs bufs; NoriHipRay *d_rays = nullptr; NoriHipHit *d_hits = nullptr; float *d_full = nullptr;
+    HIPCHK(bufs.get(d_rays, n * sizeof(NoriHipRay)));
+    HIPCHK(bufs.get(d_hits, n * sizeof(NoriHipHit)));
+    if (full) HIPCHK(bufs.get(d_full, n * 16 * sizeof(float)));
     HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream));
     unsigned blocks = (unsigned) ((n + 255) / 256);
     hipLaunchKernelGGL(k_trace, dim3(blocks), dim3(256), 0, ctx->stream, ctx->sc, (const NoriHipRay *) d_rays, n, any_hit, d_hits, d_full);
@@ -1056,7 +1068,6 @@ int nori_hip_trace(NoriHipContext *ctx, const NoriHipRay *rays, size_t n, int an
     HIPCHK(hipMemcpyAsync(hits, d_hits, n * sizeof(NoriHipHit), hipMemcpyDeviceToHost, ctx->stream));
     if (full) HIPCHK(hipMemcpyAsync(full, d_full, n * 16 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d_rays); hipFree(d_hits); hipFree(d_full);
     return NORI_HIP_OK;
 }
 
@@ -1064,15 +1075,14 @@ int nori_hip_camera_rays(NoriHipContext *ctx, const float *ps, size_t n, NoriHip
     SCENECHK(ctx);
     if (n == 0) return NORI_HIP_OK;
     if (!ps || !rays) return fail(NORI_HIP_EINVAL, "null buffer");
-    float *d_ps = nullptr; NoriHipRay *d_rays = nullptr;
-    HIPCHK(hipMalloc((void **) &d_ps, n * 2 * sizeof(float)));
-    HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay)));
+    DevBufs bufs; float *d_ps = nullptr; NoriHipRay *d_rays = nullptr;
+    HIPCHK(bufs.get(d_ps, n * 2 * sizeof(float)));
+    HIPCHK(bufs.get(d_rays, n * sizeof(NoriHipRay)));
     HIPCHK(hipMemcpyAsync(d_ps, ps, n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_camera_rays, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, (const float *) d_ps, n, d_rays);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rays, d_rays, n * sizeof(NoriHipRay), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d_ps); hipFree(d_rays);
     return NORI_HIP_OK;
 }
 
@@ -1082,13 +1092,13 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     if (n == 0) return NORI_HIP_OK;
     if (!states || !seqs || !rgb || ((px == nullptr) != (py == nullptr))) return fail(NORI_HIP_EINVAL, "null buffer");
     if (ctx->sc.n_emitters == 0 && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
-    int32_t *d_px = nullptr, *d_py = nullptr; uint64_t *d_st = nullptr, *d_sq = nullptr; NoriHipRay *d_rays = nullptr; float *d_rgb = nullptr;
-    if (px) { HIPCHK(hipMalloc((void **) &d_px, n * 4)); HIPCHK(hipMemcpyAsync(d_px, px, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
-    if (py) { HIPCHK(hipMalloc((void **) &d_py, n * 4)); HIPCHK(hipMemcpyAsync(d_py, py, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
-    HIPCHK(hipMalloc((void **) &d_st, n * 8)); HIPCHK(hipMemcpyAsync(d_st, states, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMalloc((void **) &d_sq, n * 8)); HIPCHK(hipMemcpyAsync(d_sq, seqs, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (rays) { HIPCHK(hipMalloc((void **) &d_rays, n * sizeof(NoriHipRay))); HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream)); }
-    HIPCHK(hipMalloc((void **) &d_rgb, n * 12));
+    DevBufs bufs; int32_t *d_px = nullptr, *d_py = nullptr; uint64_t *d_st = nullptr, *d_sq = nullptr; NoriHipRay *d_rays = nullptr; float *d_rgb = nullptr;
+    if (px) { HIPCHK(bufs.get(d_px, n * 4)); HIPCHK(hipMemcpyAsync(d_px, px, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
+    if (py) { HIPCHK(bufs.get(d_py, n * 4)); HIPCHK(hipMemcpyAsync(d_py, py, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
+    HIPCHK(bufs.get(d_st, n * 8)); HIPCHK(hipMemcpyAsync(d_st, states, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(bufs.get(d_sq, n * 8)); HIPCHK(hipMemcpyAsync(d_sq, seqs, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (rays) { HIPCHK(bufs.get(d_rays, n * sizeof(NoriHipRay))); HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream)); }
+    HIPCHK(bufs.get(d_rgb, n * 12));
     if (ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)
         hipLaunchKernelGGL((k_li_samples<true, true>), dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
                            (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
@@ -1101,7 +1111,6 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d_px); hipFree(d_py); hipFree(d_st); hipFree(d_sq); hipFree(d_rays); hipFree(d_rgb);
     return NORI_HIP_OK;
 }
 
@@ -1118,16 +1127,16 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced) || mats) {
         // single persistent kernel with per-lane path regeneration
         unsigned long long chunks = (job.total + MEGA_THREADS - 1) / MEGA_THREADS;
-        const int W = ctx->mega_waves;
-        unsigned blocks = (unsigned) ctx->n_cus * (unsigned) W;                    // W waves per SIMD = W workgroups of 4 waves per CU
+        const int MW = ctx->mega_waves;
+        unsigned blocks = (unsigned) ctx->n_cus * (unsigned) MW;                   // MW waves per SIMD = MW workgroups of 4 waves per CU
         if ((unsigned long long) blocks > chunks) blocks = (unsigned) chunks;
         if (blocks == 0) blocks = 1;
         const size_t stack_bytes = (size_t) (MEGA_THREADS / 64) * MEGA_DEPTH * 64 * 8;
-        const size_t share = std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) W) & ~(size_t) 1023;
+        const size_t share = std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) MW) & ~(size_t) 1023;
         const unsigned int n_cached = share > stack_bytes ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((share - stack_bytes) / 64)) : 0u;
         const size_t lds = stack_bytes + (size_t) n_cached * 64;
         void (*kern)(DevScene, RenderJob, float4 *, unsigned long long *, DevStats *, unsigned int) =
-            mats ? k_render_mats : ctx->ext ? k_render_ext : W == 3 ? k_render_w3 : W == 4 ? k_render_w4 : W == 5 ? k_render_w5 : W == 6 ? k_render_w6 : k_render_w8;
+            mats ? k_render_mats : ctx->ext ? k_render_ext : MW == 3 ? k_render_w3 : MW == 4 ? k_render_w4 : MW == 5 ? k_render_w5 : MW == 6 ? k_render_w6 : k_render_w8;
         HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(MEGA_THREADS), lds, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats, n_cached);
@@ -1279,8 +1288,8 @@ int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, flo
     size_t lds = ((size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 + (size_t) (2 * f + 1) * (2 * f + 1)) * sizeof(float);
     if (lds > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile (r + f <= 48)");
     size_t n = (size_t) W * H * 3;
-    float *d_lin = nullptr, *d_srgb = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc((void **) &d_lin, n * 4)); HIPCHK(hipMalloc((void **) &d_srgb, n * 4)); HIPCHK(hipMalloc((void **) &d_out, n * 4));
+    DevBufs bufs; float *d_lin = nullptr, *d_srgb = nullptr, *d_out = nullptr;
+    HIPCHK(bufs.get(d_lin, n * 4)); HIPCHK(bufs.get(d_srgb, n * 4)); HIPCHK(bufs.get(d_out, n * 4));
     hipLaunchKernelGGL(k_bitmap, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d_lin);
     hipLaunchKernelGGL(k_srgb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float *) d_lin, n, d_srgb);
     const char *fenv = getenv("NORI_HIP_FILTER");
@@ -1300,7 +1309,6 @@ int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, flo
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d_lin); hipFree(d_srgb); hipFree(d_out);
     return NORI_HIP_OK;
 }
 
