@@ -274,6 +274,24 @@ __global__ void k_pool_init(Pool pool, unsigned int n, WfCounters *cnt) {
 }
 __global__ void k_iter_begin(WfCounters *cnt) { CN_LIVE(cnt) = 0u; }
 
+// Once the work counter is exhausted the live paths thin out by about a quarter per bounce, while every stage still
+// sweeps the whole pool.  When fewer than half of the slots are live the host has them packed into the front of a
+// second pool of half the size (the live list of the last shade stage names them) and goes on with that one: slot
+// numbers mean nothing outside the pool, so nothing else changes.  Slots [n, n_dst) of the new pool are left inactive.
+__global__ __launch_bounds__(256) void k_compact_pool(Pool src, Pool dst, const unsigned int *q_live, const WfCounters *cnt, unsigned int n_dst) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x, n = CN_LIVE(cnt);
+    if (i >= n_dst) return;
+    if (i < n) {
+        const unsigned int s = q_live[i];
+        dst.ray_o[i] = src.ray_o[s]; dst.ray_d[i] = src.ray_d[s]; dst.hit[i] = src.hit[s]; dst.thr[i] = src.thr[s]; dst.li[i] = src.li[s];
+        dst.rng[i] = src.rng[s]; dst.pix[i] = src.pix[s]; dst.sh_o[i] = src.sh_o[s]; dst.sh_d[i] = src.sh_d[s]; dst.sh_c[i] = src.sh_c[s];
+    } else {
+        dst.li[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
+        dst.ray_d[i] = make_float4(0.f, 0.f, 0.f, -1.f); dst.ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dst.sh_d[i] = make_float4(0.f, 0.f, 0.f, -1.f); dst.sh_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // What k_shade and k_finish do with a slot before its new hit is looked at: add the NEE term of the previous bounce
 // if its shadow ray was unoccluded (src/pathMisIntegrator.cpp:150-163; the sum order of Li is the reference's: the
 // NEE term of bounce k enters before the emission term of bounce k+1).
@@ -799,7 +817,8 @@ struct NoriHipContext {
     int n_cus = 256;
     size_t lds_bytes = 65536;         // LDS a workgroup may use (sharedMemPerBlockOptin)
     // wavefront pipeline
-    unsigned int pool_slots = 0; Pool pool; void *pool_mem = nullptr;
+    unsigned int pool_slots = 0; Pool pool, pool_b; void *pool_mem = nullptr;     // pool_b: half the slots, for the compaction of the tail
+    bool compact = true;              // NORI_HIP_COMPACT=0: never pack the pool (the tail then sweeps dead slots until k_finish takes over)
     unsigned int *d_qlive = nullptr, *d_flags = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ext_ev;   // pairs of events around the extend launches since the last reset_stats
@@ -865,6 +884,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
     if (const char *e = getenv("NORI_HIP_LBVH_BIG")) { float v = (float) atof(e); if (v >= 0.f) c->lbvh_big = v; }
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
+    if (const char *e = getenv("NORI_HIP_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
@@ -1148,12 +1168,13 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     // ---- wavefront stages over a pool of path slots
     const unsigned int pool_cap = ctx->pool_slots ? ctx->pool_slots : (1u << 23);
     if (!ctx->pool_mem) {
-        const size_t P = pool_cap;
-        HIPCHK(hipMalloc(&ctx->pool_mem, P * 10 * sizeof(float4)));
-        float4 *base = (float4 *) ctx->pool_mem;
-        Pool &pl = ctx->pool;
-        pl.ray_o = base; pl.ray_d = base + P; pl.hit = (uint4 *) (base + 2 * P); pl.thr = base + 3 * P; pl.li = base + 4 * P;
-        pl.rng = (uint4 *) (base + 5 * P); pl.pix = base + 6 * P; pl.sh_o = base + 7 * P; pl.sh_d = base + 8 * P; pl.sh_c = base + 9 * P;
+        const size_t P = pool_cap, PB = ((P / 2 + 63) / 64) * 64 + 64;
+        HIPCHK(hipMalloc(&ctx->pool_mem, (P + PB) * 10 * sizeof(float4)));
+        auto carve = [](Pool &pl, float4 *base, size_t n) {
+            pl.ray_o = base; pl.ray_d = base + n; pl.hit = (uint4 *) (base + 2 * n); pl.thr = base + 3 * n; pl.li = base + 4 * n;
+            pl.rng = (uint4 *) (base + 5 * n); pl.pix = base + 6 * n; pl.sh_o = base + 7 * n; pl.sh_d = base + 8 * n; pl.sh_c = base + 9 * n;
+        };
+        carve(ctx->pool, (float4 *) ctx->pool_mem, P); carve(ctx->pool_b, (float4 *) ctx->pool_mem + 10 * P, PB);
         HIPCHK(hipMalloc((void **) &ctx->d_qlive, P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_flags, P * 4));
     }
     unsigned int P = pool_cap;
@@ -1182,8 +1203,13 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, %u nodes cached\n", trace_threads, trace_bpc, trace_lds, trace_cached);
-    const unsigned trace_blocks = std::max(1u, std::min<unsigned>((P + trace_threads - 1) / trace_threads, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
-    const unsigned shade_blocks = std::max(1u, std::min<unsigned>((P + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
+    unsigned trace_blocks = 1, shade_blocks = 1;
+    auto size_grids = [&](unsigned int slots) {
+        trace_blocks = std::max(1u, std::min<unsigned>((slots + trace_threads - 1) / trace_threads, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
+        shade_blocks = std::max(1u, std::min<unsigned>((slots + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
+    };
+    size_grids(P);
+    Pool pools[2] = {ctx->pool, ctx->pool_b}; int pi = 0;                      // the pool in use; P shrinks with every compaction
     const int SW = ctx->shade_waves;
     void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, unsigned int *, WfCounters *, unsigned long long *, DevStats *) =
         ctx->ext ? k_shade_ext : SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
@@ -1191,13 +1217,13 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     uint64_t it = 0;
     for (;; ++it) {
         hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
-        hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, P, job, ctx->d_film, ctx->d_qlive, ctx->d_flags, c, ctx->d_counter, ctx->d_stats);
+        hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, job, ctx->d_film, ctx->d_qlive, ctx->d_flags, c, ctx->d_counter, ctx->d_stats);
         {
             if (ctx->ext_used + 2 > ctx->ext_ev.size()) {
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
                 else { hipEvent_t a_, b_; HIPCHK(hipEventCreate(&a_)); HIPCHK(hipEventCreate(&b_)); ctx->ext_ev.push_back(a_); ctx->ext_ev.push_back(b_); }
             }
-#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, ctx->pool, P, ctx->d_stats, thr, trace_cached)
+#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_cached)
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
                 if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
@@ -1223,11 +1249,19 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
                 const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u)));
-                if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, ctx->pool, ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
                 ++it;
                 break;
+            }
+            if (ctx->compact && n_upper < P / 2 && P >= (1u << 17)) {
+                // (live < P means the work counter is exhausted, so the count only falls from here: the value of three
+                // iterations ago bounds the one the kernel will read)
+                const unsigned int P2 = ((P / 2 + 63u) / 64u) * 64u;
+                hipLaunchKernelGGL(k_compact_pool, dim3((P2 + 255) / 256), dim3(256), 0, ctx->stream, pools[pi], pools[pi ^ 1], (const unsigned int *) ctx->d_qlive, (const WfCounters *) c, P2);
+                HIPCHK(hipGetLastError());
+                pi ^= 1; P = P2; size_grids(P);
             }
         }
         if (it > (1ull << 24)) return fail(NORI_HIP_EDEVICE, "wavefront loop did not terminate");
