@@ -535,3 +535,26 @@ def test_film_tensor_and_rccl_all_reduce_on_the_device_film(loaded):
         assert np.array_equal(ctx.read_film(), before * 2)                      # sum over one rank
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["cbox", "table_microfacet", "cbox_subsurface"])
+def test_per_pixel_welch_t_test_against_independent_oracle_samples(name, loaded):
+    """the GPU estimator against the oracle on INDEPENDENT streams (GPU: sample indices 0..127, oracle:
+    128..255 of the same pixels), Welch's t per pixel on luminance.  Matched-stream tests elsewhere show the two follow the
+    same paths; this one shows the distributions agree where they do not."""
+    W, H, n = 64, 48, 128
+    hs, ctx = loaded(name, W, H)
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML[name]), W, H, 1)
+    rng = np.random.default_rng(31)
+    pix = rng.choice(W * H, 160, replace=False)
+    px, py = np.repeat(pix % W, n).astype(np.int32), np.repeat(pix // W, n).astype(np.int32)
+    state = (py.astype(np.uint64) * np.uint64(W) + px.astype(np.uint64))
+    seq = np.tile(np.arange(n, dtype=np.uint64), len(pix))
+    lum = np.array([0.212671, 0.715160, 0.072169], np.float32)
+    a = (ctx.li_samples(state, seq, px=px, py=py) @ lum).reshape(len(pix), n).astype(np.float64)
+    b = (o.li_samples(px, py, state, seq + np.uint64(n))[0] @ lum).reshape(len(pix), n).astype(np.float64)
+    se = np.sqrt(a.var(1, ddof=1) / n + b.var(1, ddof=1) / n)
+    ok = se > 0                                                                # pixels that see no light on either side
+    t = np.abs(a.mean(1) - b.mean(1))[ok] / se[ok]
+    assert ok.sum() > 100 and (t > 4.0).sum() == 0 and (t > 2.5).mean() < 0.05, (ok.sum(), np.sort(t)[-5:])
+    assert abs(a.mean() - b.mean()) < 4 * np.sqrt(a.var() / a.size + b.var() / b.size)
