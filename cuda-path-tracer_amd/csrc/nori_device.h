@@ -849,6 +849,58 @@ __device__ __forceinline__ bool path_bounce_mats(const DevScene &sc, const Nodes
     return true;
 }
 
+// DirectMisIntegrator::Li (src/directMisIntegrator.cpp:19-141) as one "bounce" that always ends the path: every emitter
+// sampled once, then one BSDF sample, both MIS-weighted; quirks kept as written (see the oracle's direct_mis_li).
+template <bool EXT = false, typename StackT, typename NodesT>
+__device__ __forceinline__ bool path_direct_mis(const DevScene &sc, const NodesT &nodes, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
+    Hit hit;
+    ctr.closest++;
+    if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+    Surface sf;
+    surface_from_hit<EXT>(sc, ps.ray, hit, sf, false);
+    const NoriHipShape &shp = sc.shapes[sf.shape];
+    if (shp.emitter >= 0) {
+        F3 wi = normalized(sf.p - ps.ray.o);
+        if (dot(sf.sh.n, wi) < 0) ps.li = ps.li + f3(sc.emitters[shp.emitter].radiance);
+    }
+    const F3 wi_l = sf.sh.toLocal(-ps.ray.d);
+    F3 alb = f3(shp.albedo);
+    if (EXT && shp.albedo_tex) alb = tex_color(sc, sc.textures[shp.albedo_tex - 1], sf.uv);
+    for (uint32_t e = 0; e < sc.n_emitters; ++e) {
+        const NoriHipEmitter &em = sc.emitters[e];
+        F3 lwi, ln, lp; Ray shadow;
+        F3 liLoc = emitter_sample(sc, em, sf.p, rng.next2D(), lwi, ln, lp, shadow);
+        Hit sh; ctr.shadow++;
+        if (trace<true>(sc, nodes, shadow, sh, stk, ctr.nodes, ctr.prims)) continue;
+        F3 wo_l = sf.sh.toLocal(lwi);
+        F3 f = bsdf_eval(shp, alb, wi_l, wo_l);
+        float bpdf = bsdf_pdf(shp, wi_l, wo_l);
+        float lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), sf.p, lp, ln, lwi);
+        float wem = lpdf / (lpdf + bpdf);
+        float cosS = dot(normalized(lwi), normalized(sf.sh.n));
+        if (wem > 0) ps.li = ps.li + ((wem * liLoc) * f) * cosS;
+    }
+    F2 s2 = rng.next2D(); F2 s1 = rng.next2D();
+    F3 wo; bool is_delta, wo_valid;
+    F3 f = bsdf_sample(shp, alb, wi_l, s1, s2, wo, is_delta, wo_valid);
+    if (!wo_valid) return false;
+    Ray refl; refl.o = sf.p; refl.d = sf.sh.toWorld(wo); refl.mint = 1e-4f; refl.maxt = ND_INF;
+    Hit h2; ctr.closest++;
+    if (trace<false>(sc, nodes, refl, h2, stk, ctr.nodes, ctr.prims)) {
+        Surface s2f; surface_from_hit<EXT>(sc, refl, h2, s2f, false);
+        const NoriHipShape &shp2 = sc.shapes[s2f.shape];
+        if (shp2.emitter >= 0) {
+            F3 wi = normalized(s2f.p - refl.o);
+            F3 flight = (dot(s2f.sh.n, wi) < 0) ? f3(sc.emitters[shp2.emitter].radiance) : f3(0.f);
+            float bpdf = bsdf_pdf(shp, wi_l, wo);
+            float lpdf = emitter_pdf(shape_area_pdf(sc, shp2), refl.o, s2f.p, s2f.sh.n, wi);
+            float wmat = bpdf / (lpdf + bpdf);
+            if (wmat > 0) ps.li = ps.li + (wmat * f) * flight;
+        }
+    }
+    return false;
+}
+
 template <bool EXT = false, typename StackT>
 __device__ __forceinline__ bool path_bounce(const DevScene &sc, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     GlobalNodes g; g.nodes = sc.nodes;

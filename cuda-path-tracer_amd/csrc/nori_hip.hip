@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_camera_rays(DevScene sc, const float *p
     rays[i] = o;
 }
 
-template <bool EXT, bool MATS = false>
+template <bool EXT, int KIND = NORI_HIP_INTEGRATOR_PATH_MIS>
 __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const int32_t *px, const int32_t *py, const uint64_t *states,
                                                     const uint64_t *seqs, const NoriHipRay *rays, float *rgb) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,8 +103,10 @@ __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const
     else camera_ray(sc, f2(j.x * (float) sc.cam.width, j.y * (float) sc.cam.height), ray);      // src/ttest.cpp:171-172
     PathState ps; path_init(ps, ray);
     ScratchStack stk; Counters c = {0, 0, 0, 0};
-    if (MATS) { GlobalNodes g; g.nodes = sc.nodes; while (path_bounce_mats<EXT>(sc, g, ps, rng, stk, c)) { } }
-    else while (path_bounce<EXT>(sc, ps, rng, stk, c)) { }
+    GlobalNodes g; g.nodes = sc.nodes;
+    if (KIND == NORI_HIP_INTEGRATOR_PATH_MATS) { while (path_bounce_mats<EXT>(sc, g, ps, rng, stk, c)) { } }
+    else if (KIND == NORI_HIP_INTEGRATOR_DIRECT_MIS) path_direct_mis<EXT>(sc, g, ps, rng, stk, c);
+    else while (path_bounce<EXT>(sc, g, ps, rng, stk, c)) { }
     rgb[3 * i] = ps.li.x; rgb[3 * i + 1] = ps.li.y; rgb[3 * i + 2] = ps.li.z;
 }
 
@@ -149,7 +151,7 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
 // fetch per trip), so it is built for several register budgets (waves per SIMD) and the host picks one.
 #define MEGA_THREADS 256
 #define MEGA_DEPTH 8
-template <bool EXT, bool MATS = false>
+template <bool EXT, int KIND = NORI_HIP_INTEGRATOR_PATH_MIS>
 __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob &job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     extern __shared__ float4 dyn_lds[];
     uint2 stack_spill[ND_STACK - MEGA_DEPTH];
@@ -196,7 +198,9 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
         }
         if (__ballot(alive) == 0ull) { if (exhausted && cursor >= end) break; else continue; }
         if (alive) {
-            if (!(MATS ? path_bounce_mats<EXT>(sc, nodes, ps, rng, stk, ctr) : path_bounce<EXT>(sc, nodes, ps, rng, stk, ctr))) {
+            const bool go_on = KIND == NORI_HIP_INTEGRATOR_PATH_MATS ? path_bounce_mats<EXT>(sc, nodes, ps, rng, stk, ctr)
+                             : KIND == NORI_HIP_INTEGRATOR_DIRECT_MIS ? path_direct_mis<EXT>(sc, nodes, ps, rng, stk, ctr) : path_bounce<EXT>(sc, nodes, ps, rng, stk, ctr);
+            if (!go_on) {
                 if (!film_put(sc, film, pixel_sample, px, py, ps.li)) n_invalid++;
                 alive = false;
             }
@@ -229,7 +233,10 @@ __global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     render_body<true>(sc, job, film, work_counter, stats, n_cached); }
 // NORI_HIP_INTEGRATOR_PATH_MATS (src/pathMatsIntegrator.cpp): every scene kind through one variant
 __global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_mats(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
-    render_body<true, true>(sc, job, film, work_counter, stats, n_cached); }
+    render_body<true, NORI_HIP_INTEGRATOR_PATH_MATS>(sc, job, film, work_counter, stats, n_cached); }
+// NORI_HIP_INTEGRATOR_DIRECT_MIS (src/directMisIntegrator.cpp)
+__global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_direct(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
+    render_body<true, NORI_HIP_INTEGRATOR_DIRECT_MIS>(sc, job, film, work_counter, stats, n_cached); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Wavefront pipeline: the bounce loop of PathMisIntegrator::Li cut into stages that run as separate kernels over
@@ -1058,7 +1065,7 @@ int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used
 
 int nori_hip_set_integrator(NoriHipContext *ctx, int kind) {
     CTXCHK(ctx);
-    if (kind != NORI_HIP_INTEGRATOR_PATH_MIS && kind != NORI_HIP_INTEGRATOR_PATH_MATS) return fail(NORI_HIP_EINVAL, "unknown integrator kind");
+    if (kind != NORI_HIP_INTEGRATOR_PATH_MIS && kind != NORI_HIP_INTEGRATOR_PATH_MATS && kind != NORI_HIP_INTEGRATOR_DIRECT_MIS) return fail(NORI_HIP_EINVAL, "unknown integrator kind");
     ctx->integrator = kind;
     return NORI_HIP_OK;
 }
@@ -1119,8 +1126,11 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     HIPCHK(bufs.get(d_sq, n * 8)); HIPCHK(hipMemcpyAsync(d_sq, seqs, n * 8, hipMemcpyHostToDevice, ctx->stream));
     if (rays) { HIPCHK(bufs.get(d_rays, n * sizeof(NoriHipRay))); HIPCHK(hipMemcpyAsync(d_rays, rays, n * sizeof(NoriHipRay), hipMemcpyHostToDevice, ctx->stream)); }
     HIPCHK(bufs.get(d_rgb, n * 12));
-    if (ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)
-        hipLaunchKernelGGL((k_li_samples<true, true>), dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
+    if (ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS)
+        hipLaunchKernelGGL((k_li_samples<true, NORI_HIP_INTEGRATOR_DIRECT_MIS>), dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
+                           (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
+    else if (ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)
+        hipLaunchKernelGGL((k_li_samples<true, NORI_HIP_INTEGRATOR_PATH_MATS>), dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
                            (const uint64_t *) d_st, (const uint64_t *) d_sq, (const NoriHipRay *) d_rays, d_rgb);
     else if (ctx->ext)
         hipLaunchKernelGGL(k_li_samples<true>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, n, (const int32_t *) d_px, (const int32_t *) d_py,
@@ -1143,8 +1153,8 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     RenderJob job; job.x0 = x0; job.y0 = y0; job.tw = x1 - x0; job.th = y1 - y0; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin;
     job.total = (unsigned long long) job.tw * job.th * job.nspp;
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
-    const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS;
-    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced) || mats) {
+    const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS, direct = ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS;
+    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced) || mats || direct) {
         // single persistent kernel with per-lane path regeneration
         unsigned long long chunks = (job.total + MEGA_THREADS - 1) / MEGA_THREADS;
         const int MW = ctx->mega_waves;
@@ -1156,7 +1166,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         const unsigned int n_cached = share > stack_bytes ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((share - stack_bytes) / 64)) : 0u;
         const size_t lds = stack_bytes + (size_t) n_cached * 64;
         void (*kern)(DevScene, RenderJob, float4 *, unsigned long long *, DevStats *, unsigned int) =
-            mats ? k_render_mats : ctx->ext ? k_render_ext : MW == 3 ? k_render_w3 : MW == 4 ? k_render_w4 : MW == 5 ? k_render_w5 : MW == 6 ? k_render_w6 : k_render_w8;
+            direct ? k_render_direct : mats ? k_render_mats : ctx->ext ? k_render_ext : MW == 3 ? k_render_w3 : MW == 4 ? k_render_w4 : MW == 5 ? k_render_w5 : MW == 6 ? k_render_w6 : k_render_w8;
         HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(MEGA_THREADS), lds, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats, n_cached);

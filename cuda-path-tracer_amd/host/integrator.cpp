@@ -53,7 +53,7 @@ public:
     }
     NoriHipContext *context() override { return m_ctx; }
     const FlatScene &flat() const override { return m_flat; }
-    std::string toString() const override { return m_kind == NORI_HIP_INTEGRATOR_PATH_MATS ? "PathMatsIntegrator[backend=hip/gfx950]" : "PathMisIntegrator[backend=hip/gfx950]"; }
+    std::string toString() const override { return m_kind == NORI_HIP_INTEGRATOR_PATH_MATS ? "PathMatsIntegrator[backend=hip/gfx950]" : m_kind == NORI_HIP_INTEGRATOR_DIRECT_MIS ? "DirectMisIntegrator[backend=hip/gfx950]" : "PathMisIntegrator[backend=hip/gfx950]"; }
 private:
     void need() const { if (!m_ctx) throw NoriException("path_mis: preprocess() has not run"); }
     int m_kind; int m_device = 0; bool m_deviceBvh = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
@@ -64,6 +64,7 @@ static NoriObject *PathMatsHip_create(const PropertyList &l) { return new PathMi
 static struct PathMisHip_reg { PathMisHip_reg() {
     NoriObjectFactory::registerClass("path_mis", PathMisHip_create); NoriObjectFactory::registerClass("path_mis_hip", PathMisHip_create);
     NoriObjectFactory::registerClass("path_mats", PathMatsHip_create); NoriObjectFactory::registerClass("path_mats_hip", PathMatsHip_create);
+    NoriObjectFactory::registerClass("direct_mis", [](const PropertyList &l) -> NoriObject * { return new PathMisHip(l, NORI_HIP_INTEGRATOR_DIRECT_MIS); });   // src/directMisIntegrator.cpp:147
 } } PathMisHip_reg_;
 
 /// The reference's test files also name integrators that are outside this build's scope.  They are
@@ -80,7 +81,7 @@ private:
     std::string m_name;
 };
 static struct OutOfScope_reg { OutOfScope_reg() {
-    for (const char *n : {"direct_mis", "direct_ems", "direct_mats", "direct", "av", "normals", "photonmapper"})
+    for (const char *n : { "direct_ems", "direct_mats", "direct", "av", "normals", "photonmapper"})
         NoriObjectFactory::registerClass(n, [n](const PropertyList &l) -> NoriObject * { return new OutOfScopeIntegrator(l, n); });
 } } OutOfScope_reg_;
 

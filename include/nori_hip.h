@@ -35,8 +35,8 @@ enum { NORI_HIP_BSDF_DIFFUSE = 0, NORI_HIP_BSDF_MICROFACET = 1, NORI_HIP_BSDF_DI
        NORI_HIP_BSDF_SUBSURFACE = 4 };
 enum { NORI_HIP_SHAPE_MESH = 0, NORI_HIP_SHAPE_SPHERE = 1 };
 /* integrators (src/pathMisIntegrator.cpp — the hot path; src/pathMatsIntegrator.cpp — the other path integrator of the
- * reference's own test files, BSDF sampling only) */
-enum { NORI_HIP_INTEGRATOR_PATH_MIS = 0, NORI_HIP_INTEGRATOR_PATH_MATS = 1 };
+ * reference's own test files, BSDF sampling only; src/directMisIntegrator.cpp — one bounce, emitter + BSDF sampling) */
+enum { NORI_HIP_INTEGRATOR_PATH_MIS = 0, NORI_HIP_INTEGRATOR_PATH_MATS = 1, NORI_HIP_INTEGRATOR_DIRECT_MIS = 2 };
 /* image kinds and lookup modes (cuda/nori/imagetexture.cpp.cu, bumpMap.cpp.cu, normalMap.cpp.cu; src/imagetexture.cpp) */
 enum { NORI_HIP_TEX_COLOR = 0, NORI_HIP_TEX_BUMP = 1, NORI_HIP_TEX_NORMAL = 2 };
 enum { NORI_HIP_LOOKUP_NEAREST = 0, NORI_HIP_LOOKUP_BILINEAR = 1 };
@@ -192,7 +192,7 @@ int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used
 
 /* Which Li the context's nori_hip_li_samples / nori_hip_render evaluate (default NORI_HIP_INTEGRATOR_PATH_MIS).  Replaces
  * the choice of Integrator subclass by the scene file's <integrator type="..."> (NoriObjectFactory, src/parser.cpp).
- * path_mats renders through the single-kernel pipeline. */
+ * path_mats and direct_mis render through the single-kernel pipeline. */
 int nori_hip_set_integrator(NoriHipContext *ctx, int kind);
 
 /* Closest-hit (any_hit = 0) or any-hit (any_hit != 0: hits[i].prim is 1 when occluded, NORI_HIP_MISS otherwise)

@@ -249,6 +249,8 @@ def main():
               ("cbox_subsurface", S + "/proj/cbox_subsurface.xml", 64, 48, 4096, 6),
               # subsurface on the 100 k-triangle dragon (masked probes through a depth-26 tree)
               ("dragon_ss", S + "/proj/dragon-ss.xml", 64, 48, 2048, 8),
+              # direct_mis (src/directMisIntegrator.cpp) on a subsurface slab with its own IORs
+              ("odyssey_ss", S + "/proj/odyssey_ss.xml", 64, 48, 2048, 9),
               # the other path integrator of the reference's tests (src/pathMatsIntegrator.cpp): BSDF sampling only
               ("cbox_path_mats", S + "/cbox/cbox_path_mats.xml", 64, 64, 2048, 7)]
     for sc in scenes:

@@ -48,8 +48,8 @@ int orc_test_sample_count(void *hp) { return ((Handle *) hp)->suite.sample_count
 float orc_test_significance(void *hp) { return ((Handle *) hp)->suite.significance; }
 float orc_test_reference(void *hp, int i) { return ((Handle *) hp)->suite.references[i]; }
 int orc_test_is_path_mis(void *hp, int i) { return ((Handle *) hp)->suite.scenes[i].integrator == "path_mis"; }
-// 0 path_mis, 1 path_mats, -1 anything else (not restated)
-int orc_test_integrator(void *hp, int i) { const std::string &n = ((Handle *) hp)->suite.scenes[i].integrator; return n == "path_mis" ? 0 : n == "path_mats" ? 1 : -1; }
+// 0 path_mis, 1 path_mats, 2 direct_mis, -1 anything else (not restated)
+int orc_test_integrator(void *hp, int i) { const std::string &n = ((Handle *) hp)->suite.scenes[i].integrator; return n == "path_mis" ? 0 : n == "path_mats" ? 1 : n == "direct_mis" ? 2 : -1; }
 // Runs scenes [0, n) in order with ONE default-seeded sampler carried across scenes, as src/ttest.cpp:152-156 does;
 // every scene through the integrator it names (path_mis or path_mats).
 void orc_test_run(void *hp, int only_path_mis, double *means, double *variances) {

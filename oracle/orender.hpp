@@ -601,9 +601,67 @@ inline V3 path_mats_li(const Accel &acc, Sampler &smp, const Ray &_ray, PathStat
     }
     return li;
 }
+// ---- DirectMisIntegrator::Li (src/directMisIntegrator.cpp:19-141): one bounce, every emitter sampled once + one BSDF sample
+// As written: no absolute value on the cosine of the emitter term (:80-85), the direct hit adds the full emission (:36-42),
+// the BSDF-sampled ray keeps the unnormalised direction its.toWorld(wo) (:103-106), and for delta BSDFs pdf() = 0 makes the
+// weight of the BSDF-sampled term zero (:127-133).
+inline V3 direct_mis_li(const Accel &acc, Sampler &smp, const Ray &ray, PathStats *st = nullptr) {
+    const Scene &sc = *acc.scene;
+    Intersection its;
+    if (st) st->closest++;
+    if (!acc.ray_intersect(ray, its, false, -1, st ? &st->tc : nullptr)) return mk3(0.f);
+    V3 li = mk3(0.f);
+    const Frame shFrame = its.sh; const V2 uv = its.uv;
+    const Shape &mesh = sc.shapes[its.shape];
+    if (mesh.emitter >= 0) {
+        EmitterRec q; q.ref = ray.o; q.p = its.p; q.n = its.sh.n; q.wi = normalized(its.p - ray.o);
+        li = li + emitter_eval(sc.emitters[mesh.emitter], q);
+    }
+    const Bsdf &bsdf = mesh.bsdf;
+    const V3 cam_dir = -ray.d;
+    const V3 albedo = bsdf.albedo_tex >= 0 ? image_color(sc.images[bsdf.albedo_tex], uv) : bsdf.albedo;
+    for (const Emitter &light : sc.emitters) {
+        const Shape &lshape = sc.shapes[light.shape];
+        EmitterRec q; q.ref = its.p;
+        V3 liLoc = emitter_sample(light, lshape, q, smp.next2D());
+        V3 light_dir = q.wi;
+        Intersection tmp;
+        if (st) st->shadow++;
+        if (acc.ray_intersect(q.shadowRay, tmp, true, -1, st ? &st->tc : nullptr)) continue;
+        BsdfRec br; br.wi = shFrame.toLocal(cam_dir); br.wo = shFrame.toLocal(light_dir); br.uv = uv; br.albedo = albedo;
+        V3 f = bsdf_eval(bsdf, br);
+        float bpdf = bsdf_pdf(bsdf, br);
+        float lpdf = emitter_pdf(lshape, q);
+        float wem = lpdf / (lpdf + bpdf);
+        float cosS = dot(normalized(light_dir), normalized(shFrame.n));
+        if (wem > 0) li = li + ((wem * liLoc) * f) * cosS;
+    }
+    {
+        BsdfRec br; br.wi = shFrame.toLocal(cam_dir); br.uv = uv; br.albedo = albedo;
+        V2 s2 = smp.next2D(), s1 = smp.next2D();
+        V3 f = bsdf_sample(bsdf, br, s1, s2);
+        if (!br.wo_valid) return li;                          // (the reference goes on with an uninitialised direction and a zero weight)
+        Ray refl; refl.o = its.p; refl.d = its.sh.toWorld(br.wo); refl.mint = 1e-4; refl.maxt = kInf; refl.update();
+        Intersection its2;
+        if (st) st->closest++;
+        if (acc.ray_intersect(refl, its2, false, -1, st ? &st->tc : nullptr)) {
+            const Shape &m2 = sc.shapes[its2.shape];
+            if (m2.emitter >= 0) {
+                EmitterRec q; q.ref = refl.o; q.p = its2.p; q.n = its2.sh.n; q.wi = normalized(its2.p - refl.o);
+                V3 flight = emitter_eval(sc.emitters[m2.emitter], q);
+                float bpdf = bsdf_pdf(bsdf, br);
+                float lpdf = emitter_pdf(m2, q);
+                float wmat = bpdf / (lpdf + bpdf);
+                if (wmat > 0) li = li + (wmat * f) * flight;
+            }
+        }
+    }
+    return li;
+}
 // the integrator a scene names
 inline V3 scene_li(const Accel &acc, Sampler &smp, const Ray &ray, PathStats *st = nullptr) {
     if (acc.scene->integrator == "path_mats") return path_mats_li(acc, smp, ray, st);
+    if (acc.scene->integrator == "direct_mis") return direct_mis_li(acc, smp, ray, st);
     return path_mis_li(acc, smp, ray, st);
 }
 

@@ -173,7 +173,7 @@ class OracleScene:
     def test_meta(self, i):
         L = lib()
         return dict(reference=L.orc_test_reference(self.h, i), path_mis=bool(L.orc_test_is_path_mis(self.h, i)),
-                    integrator={0: "path_mis", 1: "path_mats"}.get(L.orc_test_integrator(self.h, i)),
+                    integrator={0: "path_mis", 1: "path_mats", 2: "direct_mis"}.get(L.orc_test_integrator(self.h, i)),
                     n=L.orc_test_sample_count(self.h), significance=L.orc_test_significance(self.h))
 
     def test_run_one(self, i, state, seq, n):

@@ -18,6 +18,7 @@ SCENE_XML = {
     "dragon": "proj/dragon-diffuse.xml",
     "cbox_subsurface": "proj/cbox_subsurface.xml",       # subsurface shapes: probe rays, masked traversal (EXT kernels)
     "dragon_ss": "proj/dragon-ss.xml",                   # subsurface dragon: masked probes through the deep tree
+    "odyssey_ss": "proj/odyssey_ss.xml",                 # direct_mis integrator on a subsurface slab with its own IORs
     "cbox_path_mats": "cbox/cbox_path_mats.xml",         # path_mats integrator (k_render_mats)
 }
 # scenes with images (no reference fixtures: the reference needs OpenCV to load them; the oracle's restatement is the checker)

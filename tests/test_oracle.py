@@ -17,6 +17,7 @@ SCENE_XML = {
     "dragon": "proj/dragon-diffuse.xml",
     "cbox_subsurface": "proj/cbox_subsurface.xml",       # subsurface shapes: probe rays with the shape mask (src/subsurface.cpp)
     "dragon_ss": "proj/dragon-ss.xml",                   # subsurface dragon: masked probes through the deep tree
+    "odyssey_ss": "proj/odyssey_ss.xml",                 # direct_mis integrator on a subsurface slab with its own IORs
     "cbox_path_mats": "cbox/cbox_path_mats.xml",         # the other path integrator (src/pathMatsIntegrator.cpp)
 }
 
