@@ -815,7 +815,7 @@ struct NoriHipContext {
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
     int integrator = NORI_HIP_INTEGRATOR_PATH_MIS;   // nori_hip_set_integrator
     lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
-    uint32_t lbvh_leaf = 4;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF)
+    uint32_t lbvh_leaf = 3;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF; measured: 2-3 best on every workload)
     float lbvh_big = 0.25f;           // records longer than this fraction of the scene get their own subtree (NORI_HIP_LBVH_BIG, 0 = off)
     float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
     unsigned long long *d_counter = nullptr; DevStats *d_stats = nullptr;

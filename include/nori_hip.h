@@ -180,7 +180,7 @@ int nori_hip_destroy(NoriHipContext *ctx);
 int nori_hip_upload_scene(NoriHipContext *ctx, const NoriHipSceneDesc *desc);
 
 /* Same, but the library builds the tree itself, on the device: a linear BVH (Morton order of the records' box centres,
- * Karras 2012) with at most NORI_HIP_LBVH_LEAF (default 4) records per leaf.  desc->prims / shade_prims may come in any
+ * Karras 2012) with at most NORI_HIP_LBVH_LEAF (default 3) records per leaf.  desc->prims / shade_prims may come in any
  * order (bit 31 of shape_flags is ignored); nodes, n_nodes, root, root_min and root_max are ignored.  No counterpart
  * in the reference, whose SAH build (src/bvh.cpp:54-306) runs on the host and is what nori_hip_upload_scene expects to
  * have been done: this entry is SURVEY §8f's "GPU BVH build" for scenes whose host build would dominate (10 M

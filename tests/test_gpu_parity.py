@@ -497,7 +497,7 @@ def test_device_built_bvh_edge_cases():
         n = hd.info()["prims"]
         bi = cd.build_info()
         assert n == tris * copies + 1
-        assert (bi["n_nodes"] == 0) == (n <= 4), (n, bi)
+        assert (bi["n_nodes"] == 0) == (n <= 3), (n, bi)
         rays = cs.camera_rays((rng.random((2000, 2)) * 32).astype(np.float32))
         a, b = cs.trace(rays), cd.trace(rays)
         assert np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32))      # coincident copies: the same t, whichever copy wins
