@@ -101,6 +101,8 @@ struct DevScene {
     NoriHipCamera cam;
     float inv_w, inv_h;
     int border, film_cols;
+    const float *filt_table;           // null: the fork's single-pixel film add.  Else the 33-entry tabulated reconstruction filter
+    float filt_radius, filt_lookup;    //       of ImageBlock::init (src/block.cpp:54-64) for the filter-weighted splat (:113-128)
 };
 
 struct Ray { F3 o, d; float mint, maxt; };

@@ -137,6 +137,25 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
     if (!color_valid(v)) return false;
     int ox = (px >> 5) << 5, oy = (py >> 5) << 5;
     float fx = pos.x - 0.5f - (float) (ox - sc.border), fy = pos.y - 0.5f - (float) (oy - sc.border);
+    if (sc.filt_table) {
+        // upstream Nori's put(): every pixel within the filter radius gets value * w(x) * w(y) (src/block.cpp:113-128, the code
+        // behind this fork's early return).  With border = ceil(radius - 0.5) the rectangle of a sample never leaves its block's
+        // bordered area, so nothing is clipped and the result does not depend on the blocks.
+        const int x0 = (int) ceilf(fx - sc.filt_radius), y0 = (int) ceilf(fy - sc.filt_radius);
+        const int x1 = (int) floorf(fx + sc.filt_radius), y1 = (int) floorf(fy + sc.filt_radius);
+        const int rows = sc.cam.height + 2 * sc.border;
+        for (int y = y0; y <= y1; ++y) {
+            const float wy = sc.filt_table[(int) (fabsf((float) y - fy) * sc.filt_lookup)];
+            for (int x = x0; x <= x1; ++x) {
+                const float wx = sc.filt_table[(int) (fabsf((float) x - fx) * sc.filt_lookup)];
+                const int ix = x + ox, iy = y + oy;
+                if (ix < 0 || iy < 0 || ix >= sc.film_cols || iy >= rows) continue;
+                float *p = reinterpret_cast<float *>(film + (size_t) iy * sc.film_cols + ix);
+                unsafeAtomicAdd(p + 0, (v.x * wx) * wy); unsafeAtomicAdd(p + 1, (v.y * wx) * wy); unsafeAtomicAdd(p + 2, (v.z * wx) * wy); unsafeAtomicAdd(p + 3, (1.0f * wx) * wy);
+            }
+        }
+        return true;
+    }
     int ix = (int) fx + ox, iy = (int) fy + oy;
     float *p = reinterpret_cast<float *>(film + (size_t) iy * sc.film_cols + ix);
     unsafeAtomicAdd(p + 0, v.x); unsafeAtomicAdd(p + 1, v.y); unsafeAtomicAdd(p + 2, v.z); unsafeAtomicAdd(p + 3, 1.0f);
@@ -812,6 +831,7 @@ struct NoriHipContext {
     NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
     NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
+    float *d_filt = nullptr; float filt_radius = 0.f;   // nori_hip_set_film_filter (kept across scene uploads)
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
     int integrator = NORI_HIP_INTEGRATOR_PATH_MIS;   // nori_hip_set_integrator
     lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
@@ -921,7 +941,7 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
     hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
-    hipFree(ctx->d_qlive); hipFree(ctx->d_flags);
+    hipFree(ctx->d_qlive); hipFree(ctx->d_flags); hipFree(ctx->d_filt);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     for (hipEvent_t e : ctx->ext_ev) hipEventDestroy(e);
@@ -1045,6 +1065,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     for (int i = 0; i < 3; ++i) { sc.root_min[i] = root_min[i]; sc.root_max[i] = root_max[i]; }
     sc.cam = d->camera;
     sc.inv_w = 1.0f / (float) d->camera.width; sc.inv_h = 1.0f / (float) d->camera.height;
+    sc.filt_table = ctx->d_filt; sc.filt_radius = ctx->filt_radius; sc.filt_lookup = ctx->d_filt ? 32.0f / ctx->filt_radius : 0.f;
     ctx->border = (int) std::ceil(d->camera.filter_radius - 0.5f);
     if (ctx->border < 0) ctx->border = 0;
     ctx->film_rows = d->camera.height + 2 * ctx->border; ctx->film_cols = d->camera.width + 2 * ctx->border;
@@ -1060,6 +1081,21 @@ int nori_hip_upload_scene_build(NoriHipContext *ctx, const NoriHipSceneDesc *d) 
 int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used, uint32_t *depth, double *build_ms) {
     SCENECHK(ctx);
     if (n_nodes) *n_nodes = ctx->lbvh.n_nodes; if (n_used) *n_used = ctx->lbvh.n_used; if (depth) *depth = ctx->lbvh.depth; if (build_ms) *build_ms = ctx->lbvh.build_ms;
+    return NORI_HIP_OK;
+}
+
+int nori_hip_set_film_filter(NoriHipContext *ctx, const float *table33, float radius) {
+    CTXCHK(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!table33) { if (ctx->d_filt) hipFree(ctx->d_filt); ctx->d_filt = nullptr; ctx->filt_radius = 0.f; }
+    else {
+        if (!(radius > 0.f)) return fail(NORI_HIP_EINVAL, "filter radius must be positive");
+        if (ctx->have_scene && (int) std::ceil(radius - 0.5f) > ctx->border) return fail(NORI_HIP_EINVAL, "filter radius exceeds the film border of the uploaded scene (NoriHipCamera::filter_radius)");
+        if (!ctx->d_filt) HIPCHK(hipMalloc((void **) &ctx->d_filt, 33 * sizeof(float)));
+        HIPCHK(hipMemcpy(ctx->d_filt, table33, 33 * sizeof(float), hipMemcpyHostToDevice));
+        ctx->filt_radius = radius;
+    }
+    ctx->sc.filt_table = ctx->d_filt; ctx->sc.filt_radius = ctx->filt_radius; ctx->sc.filt_lookup = ctx->d_filt ? 32.0f / ctx->filt_radius : 0.f;
     return NORI_HIP_OK;
 }
 

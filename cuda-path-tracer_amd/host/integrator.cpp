@@ -17,7 +17,8 @@ static void hipCheck(int rc, const char *what) {
 /// GPU path tracer with multiple importance sampling.  Registered as "path_mis" (so existing scene files select
 /// it unchanged) and as "path_mis_hip".  Properties: device (int, default 0 or $NORI_HIP_DEVICE); bvh (string, "host" =
 /// the reference's SAH tree built by Scene::activate (default) or "device" = a linear BVH built on the GPU at preprocess(),
-/// default $NORI_HIP_BVH).
+/// default $NORI_HIP_BVH); film (string, "reference" = this fork's single-pixel ImageBlock::put (default) or "splat" = upstream
+/// Nori's reconstruction-filter splat, default $NORI_HIP_FILM).
 class PathMisHip : public GpuIntegrator {
 public:
     explicit PathMisHip(const PropertyList &props, int kind = NORI_HIP_INTEGRATOR_PATH_MIS) : m_kind(kind) {
@@ -27,6 +28,10 @@ public:
         std::string bvh = props.getString("bvh", benv ? benv : "host");
         if (bvh != "host" && bvh != "device") throw NoriException::format("path_mis: unknown bvh mode \"%s\" (host, device)", bvh.c_str());
         m_deviceBvh = bvh == "device";
+        const char *fenv = getenv("NORI_HIP_FILM");
+        std::string film = props.getString("film", fenv ? fenv : "reference");
+        if (film != "reference" && film != "splat") throw NoriException::format("path_mis: unknown film mode \"%s\" (reference, splat)", film.c_str());
+        m_splat = film == "splat";
     }
     bool buildsOwnBVH() const override { return m_deviceBvh; }
     ~PathMisHip() override { if (m_ctx) nori_hip_destroy(m_ctx); }
@@ -35,6 +40,14 @@ public:
         if (m_flat.desc.n_emitters == 0 && m_kind == NORI_HIP_INTEGRATOR_PATH_MIS) throw NoriException("path_mis: the scene has no emitters");
         if (!m_ctx) hipCheck(nori_hip_create(m_device, &m_ctx), "nori_hip_create");
         hipCheck(nori_hip_set_integrator(m_ctx, m_kind), "nori_hip_set_integrator");
+        if (m_splat) {
+            // film = "splat": upstream Nori's filter-weighted accumulation; the table is ImageBlock::init's (src/block.cpp:54-64)
+            const ReconstructionFilter *rf = scene->getCamera()->getReconstructionFilter();
+            float table[33]; const float radius = rf->getRadius();
+            for (int i = 0; i < 32; ++i) table[i] = rf->eval((radius * i) / 32);
+            table[32] = 0.0f;
+            hipCheck(nori_hip_set_film_filter(m_ctx, table, radius), "nori_hip_set_film_filter");
+        } else hipCheck(nori_hip_set_film_filter(m_ctx, nullptr, 0.f), "nori_hip_set_film_filter");
         if (m_deviceBvh) hipCheck(nori_hip_upload_scene_build(m_ctx, &m_flat.desc), "nori_hip_upload_scene_build");
         else hipCheck(nori_hip_upload_scene(m_ctx, &m_flat.desc), "nori_hip_upload_scene");
     }
@@ -56,7 +69,7 @@ public:
     std::string toString() const override { return m_kind == NORI_HIP_INTEGRATOR_PATH_MATS ? "PathMatsIntegrator[backend=hip/gfx950]" : m_kind == NORI_HIP_INTEGRATOR_DIRECT_MIS ? "DirectMisIntegrator[backend=hip/gfx950]" : "PathMisIntegrator[backend=hip/gfx950]"; }
 private:
     void need() const { if (!m_ctx) throw NoriException("path_mis: preprocess() has not run"); }
-    int m_kind; int m_device = 0; bool m_deviceBvh = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
+    int m_kind; int m_device = 0; bool m_deviceBvh = false, m_splat = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
 };
 static NoriObject *PathMisHip_create(const PropertyList &l) { return new PathMisHip(l); }
 // "path_mats" (src/pathMatsIntegrator.cpp:87): the same plugin with the other Li

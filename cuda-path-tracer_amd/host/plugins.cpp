@@ -412,13 +412,45 @@ private:
 };
 NORI_REGISTER_CLASS(AreaEmitter, "area")
 
-// ---- reconstruction filters (radius only: the film's border size; src/rfilter.cpp:43-135) ------------------
-class GaussianFilter : public ReconstructionFilter { public: explicit GaussianFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); m_stddev = p.getFloat("stddev", 0.5f); }
-    std::string toString() const override { char b[96]; snprintf(b, sizeof(b), "GaussianFilter[radius=%f, stddev=%f]", m_radius, m_stddev); return b; } float m_stddev; };
-class MitchellNetravaliFilter : public ReconstructionFilter { public: explicit MitchellNetravaliFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); }
-    std::string toString() const override { return "MitchellNetravaliFilter[]"; } };
-class TentFilter : public ReconstructionFilter { public: explicit TentFilter(const PropertyList &) { m_radius = 1.0f; } std::string toString() const override { return "TentFilter[]"; } };
-class BoxFilter : public ReconstructionFilter { public: explicit BoxFilter(const PropertyList &) { m_radius = 0.5f; } std::string toString() const override { return "BoxFilter[]"; } };
+// ---- reconstruction filters (src/rfilter.cpp:43-135): the radius sizes the film's border; eval() feeds the tabulated
+// filter of the optional splat mode (nori_hip_set_film_filter) ------------------------------------------------------
+class GaussianFilter : public ReconstructionFilter {
+public:
+    explicit GaussianFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); m_stddev = p.getFloat("stddev", 0.5f); }
+    float eval(float x) const override {
+        float alpha = -1.0f / (2.0f * m_stddev * m_stddev);
+        return std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * m_radius * m_radius));
+    }
+    std::string toString() const override { char b[96]; snprintf(b, sizeof(b), "GaussianFilter[radius=%f, stddev=%f]", m_radius, m_stddev); return b; }
+private:
+    float m_stddev;
+};
+class MitchellNetravaliFilter : public ReconstructionFilter {
+public:
+    explicit MitchellNetravaliFilter(const PropertyList &p) { m_radius = p.getFloat("radius", 2.0f); m_B = p.getFloat("B", 1.0f / 3.0f); m_C = p.getFloat("C", 1.0f / 3.0f); }
+    float eval(float x) const override {
+        x = std::abs(2.0f * x / m_radius);
+        float x2 = x * x, x3 = x2 * x;
+        if (x < 1) return 1.0f / 6.0f * ((12 - 9 * m_B - 6 * m_C) * x3 + (-18 + 12 * m_B + 6 * m_C) * x2 + (6 - 2 * m_B));
+        else if (x < 2) return 1.0f / 6.0f * ((-m_B - 6 * m_C) * x3 + (6 * m_B + 30 * m_C) * x2 + (-12 * m_B - 48 * m_C) * x + (8 * m_B + 24 * m_C));
+        return 0.0f;
+    }
+    std::string toString() const override { char b[128]; snprintf(b, sizeof(b), "MitchellNetravaliFilter[radius=%f, B=%f, C=%f]", m_radius, m_B, m_C); return b; }
+private:
+    float m_B, m_C;
+};
+class TentFilter : public ReconstructionFilter {
+public:
+    explicit TentFilter(const PropertyList &) { m_radius = 1.0f; }
+    float eval(float x) const override { return std::max(0.0f, 1.0f - std::abs(x)); }
+    std::string toString() const override { return "TentFilter[]"; }
+};
+class BoxFilter : public ReconstructionFilter {
+public:
+    explicit BoxFilter(const PropertyList &) { m_radius = 0.5f; }
+    float eval(float) const override { return 1.0f; }
+    std::string toString() const override { return "BoxFilter[]"; }
+};
 NORI_REGISTER_CLASS(GaussianFilter, "gaussian")
 NORI_REGISTER_CLASS(MitchellNetravaliFilter, "mitchell")
 NORI_REGISTER_CLASS(TentFilter, "tent")

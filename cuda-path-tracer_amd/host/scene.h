@@ -111,6 +111,7 @@ class ReconstructionFilter : public NoriObject {
 public:
     EClassType getClassType() const override { return EReconstructionFilter; }
     float getRadius() const { return m_radius; }
+    virtual float eval(float x) const = 0;                   // include/nori/rfilter.h:45
 protected:
     float m_radius = 2.0f;
 };

@@ -75,6 +75,8 @@ def hip_lib():
         L.nori_hip_destroy.argtypes = [vp]
         L.nori_hip_upload_scene.argtypes = [vp, vp]
         L.nori_hip_upload_scene_build.argtypes = [vp, vp]
+        L.nori_hip_set_film_filter.argtypes = [vp, vp, C.c_float]
+        L.nori_hip_set_integrator.argtypes = [vp, i32]
         L.nori_hip_build_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.nori_hip_trace.argtypes = [vp, vp, sz, i32, vp, vp]
         L.nori_hip_trace_device.argtypes = [vp, vp, sz, i32, vp]
@@ -174,6 +176,11 @@ class Context:
     def upload_build(self, desc_ptr):
         """upload with the tree built on the device (nori_hip_upload_scene_build)"""
         _hchk(self.L.nori_hip_upload_scene_build(self.h, C.cast(desc_ptr, C.c_void_p)))
+
+    def set_film_filter(self, table33=None, radius=0.0):
+        """filter-weighted splat (upstream Nori's ImageBlock::put) with the given 33-entry table, or None for the fork's film"""
+        t = None if table33 is None else np.ascontiguousarray(table33, np.float32)
+        _hchk(self.L.nori_hip_set_film_filter(self.h, _vp(t), float(radius)))
 
     def build_info(self):
         a, b, c, ms = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()

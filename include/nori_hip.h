@@ -195,6 +195,13 @@ int nori_hip_build_info(NoriHipContext *ctx, uint32_t *n_nodes, uint32_t *n_used
  * path_mats and direct_mis render through the single-kernel pipeline. */
 int nori_hip_set_integrator(NoriHipContext *ctx, int kind);
 
+/* Film accumulation mode.  table33 = the tabulated reconstruction filter ImageBlock::init builds (src/block.cpp:54-64:
+ * filter->eval(radius * i / 32) for i < 32, then 0): samples are then splatted onto every pixel within `radius` with weight
+ * w(dx) * w(dy), which is ImageBlock::put as upstream Nori has it (src/block.cpp:113-128).  In this fork that code is dead
+ * behind an early return (:107-111), and the single-pixel add before it is the default here too: table33 = NULL restores it.
+ * radius must not exceed the uploaded camera's filter_radius (the film border is sized from that). */
+int nori_hip_set_film_filter(NoriHipContext *ctx, const float *table33, float radius);
+
 /* Closest-hit (any_hit = 0) or any-hit (any_hit != 0: hits[i].prim is 1 when occluded, NORI_HIP_MISS otherwise)
  * queries for n host rays.  Replaces Scene::rayIntersect -> BVH::rayIntersect (src/bvh.cpp:404-463) including
  * Shape::setHitInformation's uv (src/mesh.cpp:137-141).  `full`, if not NULL, receives 16 floats per ray:

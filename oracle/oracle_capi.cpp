@@ -28,6 +28,7 @@ void *orc_load_scene(const char *xml_path, int width, int height, int spp) {
         if (spp > 0) h->scene.sample_count = spp;
         h->accel.build(h->scene);
         h->film.init(h->scene.camera.width, h->scene.camera.height, h->scene.camera.rfilter_radius);
+        h->film.set_filter(h->scene.camera);
         return h;
     } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
@@ -191,6 +192,9 @@ void orc_li_samples(void *hp, int si, int n, const int *px, const int *py, const
 }
 
 // ---- rendering.  mode 0 = reference block streams, 1 = per-sample streams.  Accumulates into the handle's film.
+// 1: upstream Nori's filter-weighted splat (src/block.cpp:113-128), 0: this fork's single-pixel add (default)
+void orc_film_mode(void *hp, int splat) { ((Handle *) hp)->film.splat = splat != 0; }
+void orc_film_filter_table(void *hp, float *table33, float *radius) { Handle *h = (Handle *) hp; std::memcpy(table33, h->film.table, 33 * 4); *radius = h->film.radius; }
 void orc_film_clear(void *hp) { Handle *h = (Handle *) hp; std::fill(h->film.px.begin(), h->film.px.end(), 0.f); }
 double orc_render(void *hp, int spp_begin, int spp_end, int mode, int threads, uint64_t *stats /*[5]: closest, shadow, bounces, nodes, tris or null*/) {
     Handle *h = (Handle *) hp; PathStats ps;

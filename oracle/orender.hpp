@@ -669,9 +669,32 @@ inline V3 scene_li(const Accel &acc, Sampler &smp, const Ray &ray, PathStats *st
 struct Film {
     int w = 0, h = 0, border = 0;
     std::vector<float> px;         // (h+2b) x (w+2b) x 4, row-major
+    // the tabulated reconstruction filter of ImageBlock::init (src/block.cpp:54-64); used only by the splat mode
+    bool splat = false; float radius = 0.f, lookup = 0.f, table[33];
     void init(int W, int H, float filter_radius) {
         w = W; h = H; border = (int) std::ceil(filter_radius - 0.5f);
         px.assign((size_t) (h + 2 * border) * (w + 2 * border) * 4, 0.f);
+    }
+    void set_filter(const Camera &cam) {
+        radius = cam.rfilter_radius;
+        for (int i = 0; i < 32; ++i) { float pos = (radius * i) / 32; table[i] = cam.rfilter_eval(pos); }
+        table[32] = 0.0f; lookup = 32 / radius;
+    }
+    // ImageBlock::put(sample) as UPSTREAM Nori has it: the code behind this fork's early return (src/block.cpp:113-128).
+    // Block-local coordinates as in put(); with border = ceil(radius - 0.5) the rectangle never needs clipping for a
+    // sample inside its block, so the block's borders carry the spill into the neighbours when the blocks are merged.
+    bool put_splat(V2 pos, V3 value, int ox, int oy) {
+        if (!color_valid(value)) return false;
+        float fx = pos.x - 0.5f - (float) (ox - border), fy = pos.y - 0.5f - (float) (oy - border);
+        int x0 = (int) std::ceil(fx - radius), y0 = (int) std::ceil(fy - radius), x1 = (int) std::floor(fx + radius), y1 = (int) std::floor(fy + radius);
+        for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) {
+            float wx = table[(int) (std::abs(x - fx) * lookup)], wy = table[(int) (std::abs(y - fy) * lookup)];
+            int ix = x + ox, iy = y + oy;
+            if (ix < 0 || iy < 0 || ix >= stride() || iy >= h + 2 * border) continue;
+            float *p = &px[((size_t) iy * stride() + ix) * 4];
+            p[0] += (value.x * wx) * wy; p[1] += (value.y * wx) * wy; p[2] += (value.z * wx) * wy; p[3] += (1.0f * wx) * wy;
+        }
+        return true;
     }
     int stride() const { return w + 2 * border; }
     // ImageBlock::put(sample) as written: early return after a single-pixel add (src/block.cpp:93-111), done in
@@ -679,6 +702,7 @@ struct Film {
     // whole image as ImageBlock::put(ImageBlock&) does (:131-140).  Keeping the block-local arithmetic keeps the
     // float rounding of the reference.
     bool put(V2 pos, V3 value, int ox, int oy) {
+        if (splat) return put_splat(pos, value, ox, oy);
         if (!color_valid(value)) return false;
         float fx = pos.x - 0.5f - (float) (ox - border), fy = pos.y - 0.5f - (float) (oy - border);
         int ix = (int) fx + ox, iy = (int) fy + oy;

@@ -134,6 +134,23 @@ struct Camera {
     Transform cameraToWorld, sampleToCamera;
     float invW = 0, invH = 0;
     float rfilter_radius = 2.0f;           // default gaussian (src/perspective.cpp:83-87, src/rfilter.cpp:47)
+    // the reconstruction filter itself (src/rfilter.cpp:43-135): 0 gaussian (stddev), 1 mitchell (B, C), 2 tent, 3 box
+    int rfilter_kind = 0; float rfilter_p0 = 0.5f, rfilter_p1 = 0.f;
+    float rfilter_eval(float x) const {
+        const float r = rfilter_radius;
+        switch (rfilter_kind) {
+        case 0: { float alpha = -1.0f / (2.0f * rfilter_p0 * rfilter_p0); return std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * r * r)); }
+        case 1: {
+            const float B = rfilter_p0, C = rfilter_p1;
+            x = std::abs(2.0f * x / r); float x2 = x * x, x3 = x2 * x;
+            if (x < 1) return 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+            else if (x < 2) return 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+            return 0.0f;
+        }
+        case 2: return std::max(0.0f, 1.0f - std::abs(x));
+        default: return 1.0f;
+        }
+    }
     // src/perspective.cpp:53-80
     void activate() {
         invW = 1.0f / (float) width; invH = 1.0f / (float) height;
@@ -394,8 +411,9 @@ inline Scene parse_scene(const XmlNode &node, const std::string &dir) {
             c.nearClip = pl.getf("nearClip", 1e-4f); c.farClip = pl.getf("farClip", 1e4f);
             for (auto &rf : ch.children) if (rf->name == "rfilter") {
                 Props rp; parse_props(*rf, rp); std::string ft = rf->attr("type");
-                if (ft == "gaussian" || ft == "mitchell") c.rfilter_radius = rp.getf("radius", 2.0f);
-                else if (ft == "tent") c.rfilter_radius = 1.0f; else if (ft == "box") c.rfilter_radius = 0.5f;
+                if (ft == "gaussian") { c.rfilter_kind = 0; c.rfilter_radius = rp.getf("radius", 2.0f); c.rfilter_p0 = rp.getf("stddev", 0.5f); }
+                else if (ft == "mitchell") { c.rfilter_kind = 1; c.rfilter_radius = rp.getf("radius", 2.0f); c.rfilter_p0 = rp.getf("B", 1.0f / 3.0f); c.rfilter_p1 = rp.getf("C", 1.0f / 3.0f); }
+                else if (ft == "tent") { c.rfilter_kind = 2; c.rfilter_radius = 1.0f; } else if (ft == "box") { c.rfilter_kind = 3; c.rfilter_radius = 0.5f; }
             }
             c.activate(); have_camera = true;
         } else if (t == "mesh") {

@@ -101,6 +101,15 @@ class OracleScene:
         lib().orc_image_eval(self.h, si, k, len(uv), _p(uv), _p(nrm), _p(out))
         return out
 
+    def film_mode(self, splat):
+        lib().orc_film_mode(self.h, int(bool(splat)))
+
+    def film_filter_table(self):
+        t = np.zeros(33, np.float32)
+        r = C.c_float()
+        lib().orc_film_filter_table(self.h, _p(t), C.byref(r))
+        return t, r.value
+
     def camera(self, si=0):
         s2c = np.zeros((4, 4), np.float32)
         c2w = np.zeros((4, 4), np.float32)

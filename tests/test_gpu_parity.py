@@ -559,3 +559,36 @@ def test_per_pixel_welch_t_test_against_independent_oracle_samples(name, loaded)
     t = np.abs(a.mean(1) - b.mean(1))[ok] / se[ok]
     assert ok.sum() > 100 and (t > 4.0).sum() == 0 and (t > 2.5).mean() < 0.05, (ok.sum(), np.sort(t)[-5:])
     assert abs(a.mean() - b.mean()) < 4 * np.sqrt(a.var() / a.size + b.var() / b.size)
+
+
+@pytest.mark.parametrize("pipeline", ["wavefront", "mega"])
+def test_splat_film_mode_against_oracle(pipeline):
+    """film="splat": upstream Nori's reconstruction-filter splat (src/block.cpp:113-128) instead of this fork's single-pixel add,
+    against the oracle's restatement of it on the same per-sample streams"""
+    W, H, spp = 72, 56, 8
+    xml = os.path.join(SCENES, SCENE_XML["cbox"])
+    os.environ.update(NORI_HIP_FILM="splat", NORI_HIP_PIPELINE=pipeline)
+    try:
+        hs = NH.HostScene(xml, W, H, spp)
+        ctx = hs.preprocess()
+    finally:
+        del os.environ["NORI_HIP_FILM"], os.environ["NORI_HIP_PIPELINE"]
+    ctx.clear_film(); ctx.render(0, spp)
+    film, img = ctx.read_film(), ctx.read_bitmap()
+    o = O.OracleScene(xml, W, H, spp)
+    o.film_mode(True)
+    o.render(0, spp, mode=1, threads=8)
+    ofilm, oimg = o.film(), o.bitmap()
+    assert np.allclose(film[:, :, 3], ofilm[:, :, 3], rtol=1e-4, atol=1e-5)     # filter weights: sample positions are bit-identical
+    assert film[:, :, 3].sum() > 0 and film[0, 0, 3] > 0                        # the border takes the spill of the edge pixels
+    rel = np.abs(img.mean((0, 1)) - oimg.mean((0, 1))) / oimg.mean((0, 1))
+    assert rel.max() < 1e-3, rel
+    close = np.abs(img - oimg).max(2) <= 1e-3 + 1e-2 * oimg.max(2)
+    assert close.mean() > 0.95, close.mean()
+    # and the table can be taken away again: back to the fork's film
+    ctx.set_film_filter(None)
+    ctx.clear_film(); ctx.render(0, 2)
+    assert ctx.read_film()[:, :, 3].sum() == W * H * 2
+    with pytest.raises(NH.NoriHipError, match="exceeds the film border"):
+        ctx.set_film_filter(np.ones(33, np.float32), 4.0)
+    hs.close()

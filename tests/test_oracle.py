@@ -199,3 +199,46 @@ def test_cbox_image_mean_matches_the_reference_render():
     o.render(0, 8, mode=0, threads=8)
     mean = o.bitmap().reshape(-1, 3).mean(0, dtype=np.float64)
     assert np.all(np.abs(mean - [0.150194, 0.116927, 0.125327]) < 1.5e-3), mean
+
+
+def test_splat_film_mode_is_upstream_noris_filtered_put():
+    """src/block.cpp:113-128 (dead in this fork behind the early return of :107-111): each sample goes to every pixel within
+    the filter radius with weight w(dx) w(dy) from the 32-step table of the gaussian (radius 2, stddev 0.5); checked against
+    a direct numpy evaluation for a handful of samples, and that weights stay a partition of the sample count in the mean"""
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML["cbox"]), 24, 20, 1)
+    table, radius = o.film_filter_table()
+    assert radius == 2.0 and table[32] == 0 and abs(table[0] - (1 - np.exp(-8.0))) < 1e-6
+    x = np.float32(2.0) * np.arange(32, dtype=np.float32) / np.float32(32)
+    assert np.allclose(table[:32], np.maximum(0, np.exp(-2.0 * x * x) - np.exp(-8.0)), atol=1e-7)
+    o.film_mode(True)
+    o.render(0, 3, mode=1, threads=2)
+    film = o.film()
+    o2 = O.OracleScene(os.path.join(SCENES, SCENE_XML["cbox"]), 24, 20, 1)
+    o2.render(0, 3, mode=1, threads=2)
+    ref = o2.film()
+    b = 2
+    # same samples, same radiance: the splatted film is the reference film convolved with the separable table weights
+    ys, xs = np.nonzero(ref[:, :, 3])
+    assert ref[:, :, 3].sum() == 24 * 20 * 3
+    # re-splat with numpy from the per-sample data of the oracle
+    n = 24 * 20 * 3
+    px = np.tile(np.repeat(np.arange(24), 1), 20 * 3)
+    st = []
+    li, ps = [], []
+    for s in range(3):
+        yy, xx = np.mgrid[0:20, 0:24]
+        rgb, pos = o2.li_samples(xx.ravel(), yy.ravel(), (yy.ravel() * 24 + xx.ravel()).astype(np.uint64), np.full(480, s, np.uint64))
+        li.append(rgb); ps.append(pos)
+    li, ps = np.concatenate(li), np.concatenate(ps)
+    want = np.zeros_like(film, dtype=np.float64)
+    for (sx, sy), c in zip(ps, li):
+        ox, oy = (int(sx) // 32) * 32, (int(sy) // 32) * 32
+        fx, fy = np.float32(sx) - np.float32(0.5) - np.float32(ox - b), np.float32(sy) - np.float32(0.5) - np.float32(oy - b)
+        for y in range(int(np.ceil(fy - 2)), int(np.floor(fy + 2)) + 1):
+            wy = table[int(abs(np.float32(y) - fy) * np.float32(16))]
+            for x in range(int(np.ceil(fx - 2)), int(np.floor(fx + 2)) + 1):
+                wx = table[int(abs(np.float32(x) - fx) * np.float32(16))]
+                want[y + oy, x + ox, :3] += c.astype(np.float64) * wx * wy
+                want[y + oy, x + ox, 3] += float(wx) * float(wy)
+    assert np.allclose(film, want, rtol=1e-4, atol=1e-5)
+    assert film[:, :, 3].max() < ref[:, :, 3].max() * 1.5 and film[b + 3:-b - 3, b + 3:-b - 3, 3].min() > 0
