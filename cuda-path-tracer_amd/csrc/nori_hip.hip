@@ -514,7 +514,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     uint2 stack_spill[ND_STACK - TRACE_DEPTH];
     LdsStackT<TRACE_DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + wv * (TRACE_DEPTH * 64) + lane;
     // (an LDS copy of the top of the tree, CachedNodes, was measured here: no gain, and a branch per node visit)
-    GlobalNodes nodes; nodes.nodes = sc.nodes; (void) n_cached;
+    GlobalNodes nodes; nodes.nodes = sc.nodes;
     bool any = ANY;                                                      // this lane's ray is a shadow ray
     bool l_any = ANY;                                                    // wave-uniform: kind of the batch in flight
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
@@ -593,6 +593,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         }
         if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
         if (tv.at_pop()) tv.pop_step(stk);
+        // a second box step for the lanes that stand at an inner node again (popped one, or descended into one), when enough do
+        if (n_cached) {
+            const unsigned long long m_in2 = __ballot(tv.at_inner());
+            if ((unsigned int) __popcll(m_in2) >= n_cached) {
+                if (PROF) { pf[1]++; pf[2] += __popcll(m_in2); }
+                n_boxes += 2u * (unsigned int) __popcll(m_in2);
+                const bool ord = ((KIND == TK_BOTH) ? any : ANY) || sc.ordered != 0;
+                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
+                else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
+            }
+        }
     }
     const unsigned long long v[4] = {n_rays, n_boxes, n_prims, n_rays_any};
     if (lane == 0 && (v[0] | v[1] | v[3])) {
@@ -862,6 +873,7 @@ struct NoriHipContext {
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
     bool trace_cache = false;         // (unused: the trace stage no longer caches nodes in LDS; kept so the environment knob parses)
+    int box2 = 36;                    // NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_pool step thresholds (lanes), NORI_HIP_THR
@@ -911,6 +923,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
     if (const char *e = getenv("NORI_HIP_LBVH_BIG")) { float v = (float) atof(e); if (v >= 0.f) c->lbvh_big = v; }
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
+    if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
     if (const char *e = getenv("NORI_HIP_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
     if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
@@ -1240,8 +1253,8 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (6 * 4 / trace_nw)));     // more workgroups than that run in rounds
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
-    const unsigned int trace_cached = ctx->trace_cache ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((trace_share - trace_fixed) / 64)) : 0u;
-    const size_t trace_lds = trace_fixed + (size_t) trace_cached * 64;
+    const unsigned int trace_cached = (unsigned int) ctx->box2;              // (the kernel's last argument: lanes needed for a second box step per trip, 0 = never)
+    const size_t trace_lds = trace_fixed;
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
