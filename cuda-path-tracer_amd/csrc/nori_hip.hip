@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsig
 // its ray), so an iteration has one kernel tail instead of two.
 enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 template <int KIND, bool PROF>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int n_cached) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes) {
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | slots | cached nodes
     extern __shared__ float4 dyn_lds[];
     const unsigned int nw = blockDim.x >> 6;
@@ -594,9 +594,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
         if (tv.at_pop()) tv.pop_step(stk);
         // a second box step for the lanes that stand at an inner node again (popped one, or descended into one), when enough do
-        if (n_cached) {
+        if (box2_lanes) {
             const unsigned long long m_in2 = __ballot(tv.at_inner());
-            if ((unsigned int) __popcll(m_in2) >= n_cached) {
+            if ((unsigned int) __popcll(m_in2) >= box2_lanes) {
                 if (PROF) { pf[1]++; pf[2] += __popcll(m_in2); }
                 n_boxes += 2u * (unsigned int) __popcll(m_in2);
                 const bool ord = ((KIND == TK_BOTH) ? any : ANY) || sc.ordered != 0;
@@ -872,7 +872,6 @@ struct NoriHipContext {
     bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
-    bool trace_cache = false;         // (unused: the trace stage no longer caches nodes in LDS; kept so the environment knob parses)
     int box2 = 36;                    // NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
@@ -933,7 +932,6 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_ORDER")) c->ordered = std::string(e) == "near";
     if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) c->trace_threads = v; }
-    if (const char *e = getenv("NORI_HIP_TRACE_CACHE")) c->trace_cache = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_MERGE")) c->merge_trace = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_PROFILE")) c->profile = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
@@ -1253,7 +1251,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (6 * 4 / trace_nw)));     // more workgroups than that run in rounds
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
-    const unsigned int trace_cached = (unsigned int) ctx->box2;              // (the kernel's last argument: lanes needed for a second box step per trip, 0 = never)
+    const unsigned int trace_box2 = (unsigned int) ctx->box2;
     const size_t trace_lds = trace_fixed;
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
@@ -1261,7 +1259,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, %u nodes cached\n", trace_threads, trace_bpc, trace_lds, trace_cached);
+    if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
     unsigned trace_blocks = 1, shade_blocks = 1;
     auto size_grids = [&](unsigned int slots) {
         trace_blocks = std::max(1u, std::min<unsigned>((slots + trace_threads - 1) / trace_threads, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
@@ -1282,7 +1280,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
                 else { hipEvent_t a_, b_; HIPCHK(hipEventCreate(&a_)); HIPCHK(hipEventCreate(&b_)); ctx->ext_ev.push_back(a_); ctx->ext_ev.push_back(b_); }
             }
-#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_cached)
+#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2)
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
                 if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
