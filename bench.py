@@ -234,12 +234,19 @@ def main():
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, scratch/pmc.sh), which
     # cannot run inside this process: the committed measurement of this workload and pipeline, if there is one
-    traffic = None
+    traffic, issue = None, None
     tpath = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.workload)
     if os.path.exists(tpath) and not args.spp:
         tj = json.load(open(tpath))
         if tj.get("kernel") == kname:
             traffic = int(tj["traffic_bytes_per_launch"])
+            issue = tj.get("valu_issue_busy")
+    if traffic is not None and traffic < 0.5 * alg_bytes:
+        roof_note = ("algorithmic bytes (SURVEY 8d) count every box and record test at full size; on this scene the nodes and records stay in L1/L2 "
+                     "(traffic = HBM bytes per launch from the committed PMC passes), so frac can pass 1: what bounds the kernel is vector-ALU issue "
+                     "under divergence (valu_issue_busy, same passes), see DESIGN.md 5")
+    else:
+        roof_note = "algorithmic bytes per SURVEY 8d; traffic = HBM bytes per launch from the committed PMC passes (null: not measured for this workload and pipeline)"
     out = {
         "metric": "Msamples/s (path_mis, whole node)", "value": round(total_samples / dt / 1e6, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -252,6 +259,8 @@ def main():
         "rays_per_sample": round(rays / samples_per_step, 3),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "valu_issue_busy": issue,
+                     "note": roof_note,
                      "kernel_ms": round(kernel_ms, 4), "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
                      "boxes_tested_per_ray": round(st["boxes_tested"] / args.steps / rays, 2), "prims_tested_per_ray": round(st["prims_tested"] / args.steps / rays, 2)},
     }
