@@ -326,38 +326,46 @@ __device__ __forceinline__ F3 add_pending_nee(F3 li, unsigned int flags, float4 
     return li;
 }
 
-// Shade stage.  Each block owns a contiguous run of slots and walks it twice:
-//   pass A  shades (see above) and leaves one flag word per slot (regenerate / stays live)
-//   then ONE pair of atomics per block reserves the block's camera samples and its room in the live list
-//           (per-wave totals are combined through LDS)
-//   pass B  starts new paths in the freed slots from the reserved work items (src/render.cpp:83-98) and writes the
-//           live list (used by the host for termination and by k_finish)
-enum { SF_REGEN = 1u, SF_KEEP = 2u, SF_IDLE = 4u };
+// Shade stage.  Each block owns a contiguous run of slots:
+//   pass A  shades (see above); a slot whose path goes on is appended to the block's keep list, a slot that is free
+//           afterwards to its regenerate list (both in LDS: one array of 16-bit offsets into the run, the regenerate
+//           list growing from the front, the keep list from the back; one LDS atomic pair per wave and 64 slots)
+//   then ONE pair of global atomics per block reserves the block's camera samples and its room in the live list
+//   pass B  walks the two lists densely: the keep list goes into the live list (used by the host for termination, by
+//           k_compact_pool and by k_finish), the regenerate list starts new paths from the reserved work items
+//           (src/render.cpp:83-98) with every lane busy, whatever share of the run was freed
+// The host sizes the grid so that a run has at most SHADE_RUN_MAX slots.
+#define SHADE_RUN_MAX 16384u
+enum { SL_IDLE = 0x8000u };
 template <bool EXT>
 __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, const RenderJob &job, float4 *film, unsigned int *q_live,
-                                           unsigned int *flag_buf, WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
-    __shared__ unsigned int w_tot[4][2];
+                                           WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
+    extern __shared__ unsigned short run_list[];                            // per_block entries
+    __shared__ unsigned int l_regen, l_keep;
     __shared__ unsigned long long b_work; __shared__ unsigned int b_live;
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
     const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
     const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
     const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
-    unsigned int c_regen = 0, c_keep = 0, n_invalid = 0;                    // the first two are wave-uniform
+    unsigned int n_invalid = 0;
     Counters probe_ctr = {0, 0, 0, 0};                                      // EXT: probe rays traced while shading
     const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
+    if (threadIdx.x == 0) { l_regen = 0u; l_keep = 0u; }
+    __syncthreads();
     for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
         const unsigned int slot = i0 + lane;
-        unsigned int f = 0u;
+        bool regen = false, keep = false, idle = false;
         if (slot < hi) {
             const float4 L = pool.li[slot]; const uint4 h = pool.hit[slot]; const float4 P = pool.pix[slot];
             const float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; const uint4 R = pool.rng[slot];
             const float4 C = pool.sh_c[slot];
             unsigned int flags = __float_as_uint(L.w);
-            f = SF_REGEN | SF_IDLE;
+            regen = true; idle = true;
             if (flags & PF_ACTIVE) {
                 PathState ps; ps.li = add_pending_nee(f3(L.x, L.y, L.z), flags, C);
                 bool ended = true, new_shadow = false;
+                idle = false;
                 if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
                     ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
                     ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
@@ -373,7 +381,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         pool.sh_c[slot] = make_float4(so.contrib.x, so.contrib.y, so.contrib.z, 0.f);
                     }
                     if (!so.end) {
-                        ended = false; f = SF_KEEP;
+                        ended = false;
                         pool.ray_o[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.mint);
                         pool.ray_d[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.ray.maxt);
                         pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
@@ -381,7 +389,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
                     } else if (so.has_shadow) {
                         // the path ends, but its last NEE term is still pending: it stays one more iteration without a next ray
-                        ended = false; f = SF_KEEP;
+                        ended = false;
                         pool.ray_d[slot] = no_ray;
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags | PF_ENDING));
                     }
@@ -390,21 +398,18 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                 if (ended) {
                     unsigned int pxy = __float_as_uint(P.z);
                     if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
-                    f = SF_REGEN;
-                }
+                } else { regen = false; keep = true; }
             }
-            flag_buf[slot] = f;
         }
-        c_regen += (unsigned int) __popcll(__ballot((f & SF_REGEN) != 0u));
-        c_keep += (unsigned int) __popcll(__ballot((f & SF_KEEP) != 0u));
+        const unsigned long long m_r = __ballot(regen), m_k = __ballot(keep);
+        unsigned int pr = 0, pk = 0;
+        if (lane == 0) { if (m_r) pr = atomicAdd(&l_regen, (unsigned int) __popcll(m_r)); if (m_k) pk = atomicAdd(&l_keep, (unsigned int) __popcll(m_k)); }
+        pr = __builtin_amdgcn_readfirstlane(pr); pk = __builtin_amdgcn_readfirstlane(pk);
+        if (regen) run_list[pr + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_r >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_r, 0u))] = (unsigned short) ((slot - lo) | (idle ? SL_IDLE : 0u));
+        if (keep) run_list[per_block - 1u - (pk + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_k, 0u)))] = (unsigned short) (slot - lo);
     }
-    if (lane == 0) { w_tot[wv][0] = c_regen; w_tot[wv][1] = c_keep; }
     __syncthreads();
-    unsigned int t_regen = 0, t_keep = 0, o_regen = 0, o_keep = 0;
-    for (unsigned int k = 0; k < 4; ++k) {
-        if (k == wv) { o_regen = t_regen; o_keep = t_keep; }
-        t_regen += w_tot[k][0]; t_keep += w_tot[k][1];
-    }
+    const unsigned int t_regen = l_regen, t_keep = l_keep;
     if (threadIdx.x == 0) {
         // (a plain load first: once the work has run out, the blocks stop bumping the counter)
         unsigned long long bw = padded_total;
@@ -415,42 +420,36 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     }
     __syncthreads();
     const unsigned long long base_w = b_work; const unsigned int base_n = b_live;
+    for (unsigned int k = threadIdx.x; k < t_keep; k += 256u) q_live[base_n + k] = lo + run_list[per_block - 1u - k];
     unsigned int n_samples = 0;
-    for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
-        const unsigned int slot = i0 + lane;
-        const unsigned int f = (slot < hi) ? flag_buf[slot] : 0u;
-        const unsigned long long m_r = __ballot((f & SF_REGEN) != 0u), m_k = __ballot((f & SF_KEEP) != 0u);
-        if (f & SF_KEEP) q_live[base_n + o_keep + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_k >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_k, 0u))] = slot;
-        if (f & SF_REGEN) {
-            const unsigned int r = o_regen + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_r >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_r, 0u));
-            const unsigned long long w = base_w + r;
-            if (w < padded_total) {
-                int px, py, sidx; work_to_sample(job, w, px, py, sidx);
-                if (px < job.x0 + job.tw && py < job.y0 + job.th) {
-                    Pcg32 rng; rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) sidx);
-                    F2 j = rng.next2D();
-                    F2 pixel_sample = f2((float) px + j.x, (float) py + j.y);
-                    (void) rng.next2D();
-                    Ray r0; camera_ray(sc, pixel_sample, r0);
-                    pool.ray_o[slot] = make_float4(r0.o.x, r0.o.y, r0.o.z, r0.mint);
-                    pool.ray_d[slot] = make_float4(r0.d.x, r0.d.y, r0.d.z, r0.maxt);
-                    pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
-                    pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
-                    pool.pix[slot] = make_float4(pixel_sample.x, pixel_sample.y, __uint_as_float((unsigned int) px | ((unsigned int) py << 16)), 0.f);
-                    pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(PF_ACTIVE | PF_LAST_DELTA));
-                    n_samples++;
-                } else {
-                    // padding of an edge patch: the slot counts as live, idle, and draws again in the next iteration
-                    pool.ray_d[slot] = no_ray;
-                    pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
-                }
-                q_live[base_n + t_keep + (unsigned int) (w - base_w)] = slot;
-            } else if (!(f & SF_IDLE)) {
-                pool.ray_d[slot] = no_ray;                                            // no work left: the slot retires
+    for (unsigned int r = threadIdx.x; r < t_regen; r += 256u) {
+        const unsigned int e = run_list[r], slot = lo + (e & 0x7fffu);
+        const unsigned long long w = base_w + r;
+        if (w < padded_total) {
+            int px, py, sidx; work_to_sample(job, w, px, py, sidx);
+            if (px < job.x0 + job.tw && py < job.y0 + job.th) {
+                Pcg32 rng; rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) sidx);
+                F2 j = rng.next2D();
+                F2 pixel_sample = f2((float) px + j.x, (float) py + j.y);
+                (void) rng.next2D();
+                Ray r0; camera_ray(sc, pixel_sample, r0);
+                pool.ray_o[slot] = make_float4(r0.o.x, r0.o.y, r0.o.z, r0.mint);
+                pool.ray_d[slot] = make_float4(r0.d.x, r0.d.y, r0.d.z, r0.maxt);
+                pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+                pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
+                pool.pix[slot] = make_float4(pixel_sample.x, pixel_sample.y, __uint_as_float((unsigned int) px | ((unsigned int) py << 16)), 0.f);
+                pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(PF_ACTIVE | PF_LAST_DELTA));
+                n_samples++;
+            } else {
+                // padding of an edge patch: the slot counts as live, idle, and draws again in the next iteration
+                pool.ray_d[slot] = no_ray;
                 pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
             }
+            q_live[base_n + t_keep + r] = slot;
+        } else if (!(e & SL_IDLE)) {
+            pool.ray_d[slot] = no_ray;                                            // no work left: the slot retires
+            pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
         }
-        o_regen += (unsigned int) __popcll(m_r); o_keep += (unsigned int) __popcll(m_k);
     }
     unsigned long long v0 = n_samples, v1 = n_invalid;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
@@ -464,16 +463,16 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
 // built for several register budgets (waves per SIMD); the stage is bound by the latency of its dependent fetches
 #define ND_SHADE_KERNEL(W) \
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) \
-void k_shade_w##W(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, unsigned int *flag_buf, WfCounters *cnt, \
-                  unsigned long long *work_counter, DevStats *stats) { shade_body<false>(sc, pool, n_slots, job, film, q_live, flag_buf, cnt, work_counter, stats); }
+void k_shade_w##W(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, WfCounters *cnt, \
+                  unsigned long long *work_counter, DevStats *stats) { shade_body<false>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats); }
 ND_SHADE_KERNEL(3)
 ND_SHADE_KERNEL(4)
 ND_SHADE_KERNEL(5)
 ND_SHADE_KERNEL(6)
 ND_SHADE_KERNEL(8)
-__global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, unsigned int *flag_buf,
+__global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
                                                    WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
-    shade_body<true>(sc, pool, n_slots, job, film, q_live, flag_buf, cnt, work_counter, stats); }
+    shade_body<true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats); }
 
 // Trace stage: persistent waves over the pool.  Wave w of W takes the 64-slot batches w, w+W, w+2W, ... (a static,
 // interleaved share: no shared counter).  Rays reach the lanes through a small pipeline, so that the HBM latency of
@@ -857,7 +856,7 @@ struct NoriHipContext {
     // wavefront pipeline
     unsigned int pool_slots = 0; Pool pool, pool_b; void *pool_mem = nullptr;     // pool_b: half the slots, for the compaction of the tail
     bool compact = true;              // NORI_HIP_COMPACT=0: never pack the pool (the tail then sweeps dead slots until k_finish takes over)
-    unsigned int *d_qlive = nullptr, *d_flags = nullptr; WfCounters *d_cnt = nullptr;
+    unsigned int *d_qlive = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ext_ev;   // pairs of events around the extend launches since the last reset_stats
     size_t ext_used = 0; double ext_ms_acc = 0.0; uint64_t ext_launches = 0;
@@ -952,7 +951,7 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
     hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
-    hipFree(ctx->d_qlive); hipFree(ctx->d_flags); hipFree(ctx->d_filt);
+    hipFree(ctx->d_qlive); hipFree(ctx->d_filt);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     for (hipEvent_t e : ctx->ext_ev) hipEventDestroy(e);
@@ -1232,7 +1231,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
             pl.rng = (uint4 *) (base + 5 * n); pl.pix = base + 6 * n; pl.sh_o = base + 7 * n; pl.sh_d = base + 8 * n; pl.sh_c = base + 9 * n;
         };
         carve(ctx->pool, (float4 *) ctx->pool_mem, P); carve(ctx->pool_b, (float4 *) ctx->pool_mem + 10 * P, PB);
-        HIPCHK(hipMalloc((void **) &ctx->d_qlive, P * 4)); HIPCHK(hipMalloc((void **) &ctx->d_flags, P * 4));
+        HIPCHK(hipMalloc((void **) &ctx->d_qlive, P * 4));
     }
     unsigned int P = pool_cap;
     if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, (job.total / 4 + 65535) & ~65535ull));
@@ -1260,21 +1259,24 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
-    unsigned trace_blocks = 1, shade_blocks = 1;
+    unsigned trace_blocks = 1, shade_blocks = 1; size_t shade_lds = 0;
+    auto shade_run = [](unsigned int slots, unsigned int blocks) { return (((slots + blocks - 1) / blocks) + 255u) & ~255u; };   // = per_block in shade_body
     auto size_grids = [&](unsigned int slots) {
         trace_blocks = std::max(1u, std::min<unsigned>((slots + trace_threads - 1) / trace_threads, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
         shade_blocks = std::max(1u, std::min<unsigned>((slots + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
+        if (shade_run(slots, shade_blocks) > SHADE_RUN_MAX) shade_blocks = (slots + (SHADE_RUN_MAX - 256u) - 1) / (SHADE_RUN_MAX - 256u);   // 16-bit offsets in the run lists
+        shade_lds = (size_t) shade_run(slots, shade_blocks) * sizeof(unsigned short);
     };
     size_grids(P);
     Pool pools[2] = {ctx->pool, ctx->pool_b}; int pi = 0;                      // the pool in use; P shrinks with every compaction
     const int SW = ctx->shade_waves;
-    void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, unsigned int *, WfCounters *, unsigned long long *, DevStats *) =
+    void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, WfCounters *, unsigned long long *, DevStats *) =
         ctx->ext ? k_shade_ext : SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     uint64_t it = 0;
     for (;; ++it) {
         hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
-        hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, job, ctx->d_film, ctx->d_qlive, ctx->d_flags, c, ctx->d_counter, ctx->d_stats);
+        hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), shade_lds, ctx->stream, ctx->sc, pools[pi], P, job, ctx->d_film, ctx->d_qlive, c, ctx->d_counter, ctx->d_stats);
         {
             if (ctx->ext_used + 2 > ctx->ext_ev.size()) {
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
