@@ -174,6 +174,8 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="4096", NORI_HIP_FINISH="1", NORI_HIP_THR="24,16,16"),   # stages to the last path
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="1000", NORI_HIP_FINISH="900"),       # ragged pool, early hand-over
                dict(NORI_HIP_PIPELINE="wavefront"),
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_BOX2="0", NORI_HIP_COMPACT="0"),            # one box step per trip, no pool compaction
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_BOX2="1", NORI_HIP_SHADE_BPC="1", NORI_HIP_MERGE="0"),   # always two; one run per CU; separate trace stages
                dict(NORI_HIP_PIPELINE="mega"),
                dict(NORI_HIP_PIPELINE="mega", NORI_HIP_MEGA_WAVES="6", NORI_HIP_LDS="20480")]
     for env in configs:
@@ -191,6 +193,10 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
         assert np.array_equal(f[:, :, 3], films[0][:, :, 3])
         assert np.allclose(f, films[0], rtol=1e-4, atol=1e-5)
         for k in ("camera_samples", "closest_rays", "shadow_rays", "invalid_samples"):
+            assert st[k] == stats[0][k], (k, st[k], stats[0][k])
+    # how the steps of a traversal are scheduled changes no ray's sequence of box and record tests
+    for st in stats[1:6]:
+        for k in ("boxes_tested", "prims_tested"):
             assert st[k] == stats[0][k], (k, st[k], stats[0][k])
     assert stats[0]["camera_samples"] == W * H * spp and stats[0]["iterations"] > 10
 
