@@ -177,6 +177,7 @@ struct CachedNodes {
 
 template <bool ANY> struct Trav {
     F3 o, d, rcp; float mint, maxt; uint32_t cur; int sp; Hit hit; bool found;
+    float cur_near;    // entry distance of the box of `cur` (read by the speculative trace stage only, dead code elsewhere)
     bool special;      // a direction component is zero, denormal or NaN: box tests take the general path
 
     __device__ __forceinline__ bool at_inner() const { return cur < ND_POP; }
@@ -204,7 +205,8 @@ template <bool ANY> struct Trav {
     template <typename StackT> __device__ __forceinline__ void pop_step(StackT &stk) {
         if (sp == 0) { cur = ND_DONE; return; }
         uint2 e = stk.pop(--sp);
-        cur = (__uint_as_float(e.y) <= maxt) ? e.x : ND_POP;
+        const float en = __uint_as_float(e.y); const bool ok = en <= maxt;
+        cur = ok ? e.x : ND_POP; cur_near = ok ? en : cur_near;      // (conditional on purpose: as a plain copy of e the pair {cur, cur_near} ends up in scratch memory)
     }
     // The same node visit for rays whose direction components are all normal numbers (`special` false).  Then every
     // reciprocal is finite, no product can be NaN, and the reference's compare-and-select chains (include/nori/
@@ -234,7 +236,7 @@ template <bool ANY> struct Trav {
         bool hr = (nrr <= fr) & (mint <= fr) & (nrr <= maxt) & (right != NORI_HIP_NO_CHILD);
         const bool sw = ordered & hl & hr & (nrr < nl);                  // ordered mode: the right child is entered first
         if (hl & hr) stk.push(sp++, make_uint2(sw ? left : right, __float_as_uint(sw ? nl : nrr)));
-        cur = hl ? (sw ? right : left) : (hr ? right : ND_POP);
+        cur = hl ? (sw ? right : left) : (hr ? right : ND_POP); cur_near = (hl & !sw) ? nl : nrr;
     }
     template <typename StackT, typename NodesT> __device__ __forceinline__ void box_step(const NodesT &nodes, StackT &stk, uint32_t &n_boxes, const bool ordered = false) {
         float4 n0, n1, n2, n3; nodes.fetch(cur, n0, n1, n2, n3);
@@ -250,7 +252,7 @@ template <bool ANY> struct Trav {
         bool hr = slab(rmin, rmax, o, d, rcp, mint, maxt, nrr) & (right != NORI_HIP_NO_CHILD);
         const bool sw = ordered & hl & hr & (nrr < nl);
         if (hl & hr) stk.push(sp++, make_uint2(sw ? left : right, __float_as_uint(sw ? nl : nrr)));
-        cur = hl ? (sw ? right : left) : (hr ? right : ND_POP);
+        cur = hl ? (sw ? right : left) : (hr ? right : ND_POP); cur_near = (hl & !sw) ? nl : nrr;
     }
     // one record of the current leaf; afterwards the lane is at the next record, in ND_POP (leaf finished) or done
     __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) { prim_step(sc, n_prims, ANY); }

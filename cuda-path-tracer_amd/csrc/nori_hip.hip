@@ -493,7 +493,13 @@ __global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsig
 // the pool in one launch (batches [0, NB) are shadow batches, [NB, 2 NB) extend batches; a lane carries the kind of
 // its ray), so an iteration has one kernel tail instead of two.
 enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
-template <int KIND, bool PROF>
+// SPEC (speculative traversal): a lane that reaches a leaf parks it (`pend`) and goes on traversing; the record step runs
+// for the parked leaves once thr.y lanes have one (or no lane can traverse), so it runs fuller and less often.  While a
+// leaf is parked the lane's box tests use a maxt that its records may yet shrink, which only lets more boxes pass.  The
+// reference tests a leaf's box when it gets to it, after every earlier leaf (src/bvh.cpp:404-463): a lane parks its next
+// leaf only when the parked one is finished, and re-tests the entry distance against maxt at that moment - the same
+// test at the same point of the depth-first order, so the same records are tested with the same maxt, in the same order.
+template <int KIND, bool PROF, bool SPEC = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes) {
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | slots | cached nodes
     extern __shared__ float4 dyn_lds[];
@@ -518,6 +524,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     bool l_any = ANY;                                                    // wave-uniform: kind of the batch in flight
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
     bool have = false; unsigned int slot = 0;
+    uint32_t pend = 0u;                                                  // SPEC: the parked leaf's next record (NORI_HIP_LEAF_BIT | position), 0 = none
     // statistics are wave-uniform sums of ballots (scalar registers): records and boxes tested, rays by kind
     unsigned int n_boxes = 0, n_prims = 0, n_rays = 0, n_rays_any = 0;
     uint32_t dummy = 0;
@@ -545,11 +552,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
             loading = true; b_next += n_waves;
         }
         // ---- retire finished rays, hand out staged ones
-        const unsigned long long fin = __ballot(tv.done());              // finished or never started
+        const unsigned long long fin = __ballot(tv.done() && (!SPEC || pend == 0u));   // finished or never started
         if (PROF) { pf[0]++; pf[9] += 64 - __popcll(fin); }
         if (fin && (__popcll(fin) >= thr.z || fin == ~0ull)) {
-            if (PROF) { pf[7]++; pf[8] += __popcll(__ballot(have && tv.done())); }
-            if (have && tv.done()) {
+            if (PROF) { pf[7]++; pf[8] += __popcll(__ballot(have && tv.done() && (!SPEC || pend == 0u))); }
+            if (have && tv.done() && (!SPEC || pend == 0u)) {
                 if ((KIND == TK_BOTH) ? any : ANY) { if (!tv.found) reinterpret_cast<float *>(pool.sh_c + slot)[3] = 1.0f; }
                 else pool.hit[slot] = make_uint4(tv.hit.pos, __float_as_uint(tv.hit.t), __float_as_uint(tv.hit.u), __float_as_uint(tv.hit.v));
                 have = false;
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
             if (s_pos < s_n) {
                 const unsigned int idx = s_pos + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
                 bool began = false; uint32_t root_tested = 0;
-                if (tv.done() && idx < s_n) {
+                if (tv.done() && (!SPEC || pend == 0u) && idx < s_n) {
                     const float4 ro = st_o[idx], rd = st_d[idx]; slot = st_slot[idx];
                     if (KIND == TK_BOTH) { any = (slot >> 31) != 0u; slot &= 0x7fffffffu; }
                     Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
@@ -584,11 +591,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
             else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
             ran = true;
         }
-        const unsigned long long m_lf = __ballot(tv.at_leaf());
-        if (m_lf && (__popcll(m_lf) >= thr.y || !ran)) {
-            if (PROF) { pf[3]++; pf[4] += __popcll(m_lf); }
-            n_prims += (unsigned int) __popcll(m_lf);
-            if (tv.at_leaf()) tv.prim_step(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
+        if (!SPEC) {
+            const unsigned long long m_lf = __ballot(tv.at_leaf());
+            if (m_lf && (__popcll(m_lf) >= thr.y || !ran)) {
+                if (PROF) { pf[3]++; pf[4] += __popcll(m_lf); }
+                n_prims += (unsigned int) __popcll(m_lf);
+                if (tv.at_leaf()) tv.prim_step(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
+            }
         }
         if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
         if (tv.at_pop()) tv.pop_step(stk);
@@ -601,6 +610,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
                 const bool ord = ((KIND == TK_BOTH) ? any : ANY) || sc.ordered != 0;
                 if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
                 else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
+            }
+        }
+        if (SPEC) {
+            // park the leaf the lane stands at, if the previous one is finished and its box still passes
+            if (pend == 0u && tv.at_leaf()) { if (tv.cur_near <= tv.maxt) pend = tv.cur; tv.cur = ND_POP; }
+            const unsigned long long m_pd = __ballot(pend != 0u);
+            if (m_pd && (__popcll(m_pd) >= thr.y || !ran || __ballot(tv.at_inner() || tv.at_pop()) == 0ull)) {     // (!ran: every trip runs a step)
+                if (PROF) { pf[3]++; pf[4] += __popcll(m_pd); }
+                n_prims += (unsigned int) __popcll(m_pd);
+                if (pend != 0u) {
+                    const uint32_t where = tv.cur;
+                    tv.cur = pend;
+                    tv.prim_step(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
+                    if (tv.cur == ND_DONE) pend = 0u;                                  // any-hit ray found its occluder
+                    else { pend = (tv.cur == ND_POP) ? 0u : tv.cur; tv.cur = where; }
+                }
+                if (pend == 0u && tv.at_leaf()) { if (tv.cur_near <= tv.maxt) pend = tv.cur; tv.cur = ND_POP; }
             }
         }
     }
@@ -871,10 +897,11 @@ struct NoriHipContext {
     bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
+    bool spec = true;                 // NORI_HIP_SPEC=0: no speculative traversal in the merged trace stage
     int box2 = 36;                    // NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
-    int thr_box = 1, thr_prim = 1, thr_refill = 8;   // k_trace_pool step thresholds (lanes), NORI_HIP_THR
+    int thr_box = 1, thr_prim = 1, thr_refill = 12;   // k_trace_pool step thresholds (lanes), NORI_HIP_THR
     // adds the elapsed time of the recorded extend launches to ext_ms_acc (waits for them)
     int fold_ext_events() {
         for (size_t k = 0; k + 1 < ext_used; k += 2) {
@@ -921,6 +948,7 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
     if (const char *e = getenv("NORI_HIP_LBVH_BIG")) { float v = (float) atof(e); if (v >= 0.f) c->lbvh_big = v; }
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
+    if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
     if (const char *e = getenv("NORI_HIP_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
@@ -1256,6 +1284,8 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
@@ -1285,7 +1315,10 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
 #define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2)
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
-                if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
+                if (ctx->spec) {
+                    if (ctx->profile) hipLaunchKernelGGL((k_trace_pool<TK_BOTH, true, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2);
+                    else hipLaunchKernelGGL((k_trace_pool<TK_BOTH, false, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2);
+                } else if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used + 1], ctx->stream));
             } else {
                 if (ctx->profile) ND_TRACE(TK_SHADOW, true); else ND_TRACE(TK_SHADOW, false);
