@@ -197,7 +197,17 @@ template <bool ANY> struct Trav {
         if (maxt < mint) return false;
         rcp = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         float nr; n_boxes++;
-        if (!slab(sc.root_min, sc.root_max, o, d, rcp, mint, maxt, nr)) return false;
+        bool in;
+        if (!special) {
+            // all direction components are normal numbers: the same decision by min/max, as in box_compute_fast
+            float x1 = (sc.root_min[0] - o.x) * rcp.x, x2 = (sc.root_max[0] - o.x) * rcp.x;
+            float y1 = (sc.root_min[1] - o.y) * rcp.y, y2 = (sc.root_max[1] - o.y) * rcp.y;
+            float z1 = (sc.root_min[2] - o.z) * rcp.z, z2 = (sc.root_max[2] - o.z) * rcp.z;
+            nr = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fminf(z1, z2));
+            float fr = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
+            in = (nr <= fr) & (mint <= fr) & (nr <= maxt);
+        } else in = slab(sc.root_min, sc.root_max, o, d, rcp, mint, maxt, nr);
+        if (!in) return false;
         cur = sc.root;
         return true;
     }
