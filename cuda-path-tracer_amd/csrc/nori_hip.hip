@@ -501,13 +501,13 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // test at the same point of the depth-first order, so the same records are tested with the same maxt, in the same order.
 template <int KIND, bool PROF, bool SPEC = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes) {
-    // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | slots | cached nodes
+    // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
     extern __shared__ float4 dyn_lds[];
     const unsigned int nw = blockDim.x >> 6;
     float4 *st_o_all = dyn_lds + nw * (TRACE_DEPTH * 64 * 8 / 16);
-    float4 *st_d_all = st_o_all + nw * 64;
-    unsigned int *st_slot_all = reinterpret_cast<unsigned int *>(st_d_all + nw * 64);
-    float4 *const st_o = st_o_all + (threadIdx.x >> 6) * 64, *const st_d = st_d_all + (threadIdx.x >> 6) * 64;
+    float4 *st_d_all = st_o_all + nw * 64, *st_r_all = st_d_all + nw * 64;
+    unsigned int *st_slot_all = reinterpret_cast<unsigned int *>(st_r_all + nw * 64);
+    float4 *const st_o = st_o_all + (threadIdx.x >> 6) * 64, *const st_d = st_d_all + (threadIdx.x >> 6) * 64, *const st_r = st_r_all + (threadIdx.x >> 6) * 64;
     unsigned int *const st_slot = st_slot_all + (threadIdx.x >> 6) * 64;
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     constexpr bool ANY = (KIND == TK_SHADOW);
@@ -535,11 +535,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         b_next = __builtin_amdgcn_readfirstlane(b_next); l_base = __builtin_amdgcn_readfirstlane(l_base);
         // ---- feed the staging pipeline
         if (s_pos >= s_n && loading) {
+            // The batch has arrived.  The start of a traversal (adaptive epsilon, reciprocal direction, root box:
+            // Trav::begin) is done here, with all the batch's lanes busy, and not when a ray is handed to a lane, where a
+            // dozen lanes would do it; rays that do not enter the tree are answered on the spot and never staged.
             const bool valid = !(ld4.w < lo4.w);
-            const unsigned long long m = __ballot(valid);
+            Trav<ANY> tb; uint32_t root_tested = 0; bool enters = false;
             if (valid) {
+                Ray r; r.o = f3(lo4.x, lo4.y, lo4.z); r.mint = lo4.w; r.d = f3(ld4.x, ld4.y, ld4.z); r.maxt = ld4.w;
+                enters = tb.begin(sc, r, root_tested);
+                if (!enters) {
+                    if ((KIND == TK_BOTH) ? l_any : ANY) reinterpret_cast<float *>(pool.sh_c + l_base + lane)[3] = 1.0f;
+                    else pool.hit[l_base + lane] = make_uint4(0xffffffffu, __float_as_uint(ND_INF), 0u, 0u);
+                }
+            }
+            n_boxes += (unsigned int) __popcll(__ballot(root_tested != 0u));
+            if ((KIND == TK_BOTH) ? l_any : false) n_rays_any += (unsigned int) __popcll(__ballot(valid)); else n_rays += (unsigned int) __popcll(__ballot(valid));
+            const unsigned long long m = __ballot(enters);
+            if (enters) {
                 const unsigned int r = __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
-                st_o[r] = lo4; st_d[r] = ld4; st_slot[r] = (l_base + lane) | ((KIND == TK_BOTH && l_any) ? 0x80000000u : 0u);
+                st_o[r] = make_float4(lo4.x, lo4.y, lo4.z, tb.mint); st_d[r] = ld4; st_r[r] = make_float4(tb.rcp.x, tb.rcp.y, tb.rcp.z, 0.f);
+                st_slot[r] = (l_base + lane) | ((KIND == TK_BOTH && l_any) ? 0x80000000u : 0u) | (tb.special ? 0x40000000u : 0u);
             }
             s_n = (unsigned int) __popcll(m); s_pos = 0; loading = false;
         }
@@ -563,17 +578,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
             }
             if (s_pos < s_n) {
                 const unsigned int idx = s_pos + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
-                bool began = false; uint32_t root_tested = 0;
                 if (tv.done() && (!SPEC || pend == 0u) && idx < s_n) {
-                    const float4 ro = st_o[idx], rd = st_d[idx]; slot = st_slot[idx];
-                    if (KIND == TK_BOTH) { any = (slot >> 31) != 0u; slot &= 0x7fffffffu; }
-                    Ray r; r.o = f3(ro.x, ro.y, ro.z); r.mint = ro.w; r.d = f3(rd.x, rd.y, rd.z); r.maxt = rd.w;
-                    have = true; began = true;
-                    tv.begin(sc, r, root_tested);
+                    const float4 ro = st_o[idx], rd = st_d[idx], rr = st_r[idx]; slot = st_slot[idx];
+                    if (KIND == TK_BOTH) any = (slot >> 31) != 0u;
+                    tv.special = (slot & 0x40000000u) != 0u; slot &= 0x3fffffffu;
+                    tv.o = f3(ro.x, ro.y, ro.z); tv.mint = ro.w; tv.d = f3(rd.x, rd.y, rd.z); tv.maxt = rd.w; tv.rcp = f3(rr.x, rr.y, rr.z);
+                    tv.sp = 0; tv.found = false; tv.cur = sc.root;
+                    tv.hit.pos = 0xffffffffu; tv.hit.t = ND_INF; tv.hit.u = tv.hit.v = 0.f;
+                    have = true;
                 }
-                n_boxes += (unsigned int) __popcll(__ballot(root_tested != 0u));
-                n_rays_any += (unsigned int) __popcll(__ballot(began && KIND == TK_BOTH && any));
-                n_rays += (unsigned int) __popcll(__ballot(began && !(KIND == TK_BOTH && any)));
                 s_pos += (unsigned int) __popcll(fin);
             }
             if (!loading && s_pos >= s_n && b_next >= n_batches && __ballot(have) == 0ull) break;   // nothing staged, loading or in flight
@@ -1272,7 +1285,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     // the trace stages give every wave a static share of the pool, so all their workgroups must be resident at once.
     // LDS of a workgroup: stacks + staging buffers of its waves, the rest of its share caches the top of the tree.
     const unsigned trace_threads = (unsigned) ctx->trace_threads, trace_nw = trace_threads / 64;
-    const size_t trace_fixed = (size_t) trace_nw * (TRACE_DEPTH * 64 * 8 + 64 * 36);
+    const size_t trace_fixed = (size_t) trace_nw * (TRACE_DEPTH * 64 * 8 + 64 * 52);      // stacks + staged rays (origin, direction, reciprocal direction, slot)
     int trace_bpc = ctx->trace_blocks_per_cu;
     if (trace_bpc == 0) trace_bpc = std::max(1, std::min<int>((int) (6 * 4 / trace_nw), (int) (163840 / trace_fixed)));      // 6 waves per SIMD (80 VGPRs)
     const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (6 * 4 / trace_nw)));     // more workgroups than that run in rounds
