@@ -208,7 +208,7 @@ template <bool ANY> struct Trav {
             in = (nr <= fr) & (mint <= fr) & (nr <= maxt);
         } else in = slab(sc.root_min, sc.root_max, o, d, rcp, mint, maxt, nr);
         if (!in) return false;
-        cur = sc.root;
+        cur = sc.root; cur_near = nr;        // (a scene of one leaf has no inner node: the root reference is that leaf)
         return true;
     }
     // an entry is skipped when its box no longer passes with the current maxt (then the lane stays in ND_POP)

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
                     if (KIND == TK_BOTH) any = (slot >> 31) != 0u;
                     tv.special = (slot & 0x40000000u) != 0u; slot &= 0x3fffffffu;
                     tv.o = f3(ro.x, ro.y, ro.z); tv.mint = ro.w; tv.d = f3(rd.x, rd.y, rd.z); tv.maxt = rd.w; tv.rcp = f3(rr.x, rr.y, rr.z);
-                    tv.sp = 0; tv.found = false; tv.cur = sc.root;
+                    tv.sp = 0; tv.found = false; tv.cur = sc.root; tv.cur_near = -ND_INF;       // (the root box was tested at staging; the root may be a leaf)
                     tv.hit.pos = 0xffffffffu; tv.hit.t = ND_INF; tv.hit.u = tv.hit.v = 0.f;
                     have = true;
                 }

@@ -197,17 +197,43 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
         assert np.allclose(f, films[0], rtol=1e-4, atol=1e-5)
         for k in ("camera_samples", "closest_rays", "shadow_rays", "invalid_samples"):
             assert st[k] == stats[0][k], (k, st[k], stats[0][k])
-    # How the steps of a traversal are scheduled changes no ray's sequence of record tests.  Speculative traversal (the
-    # default of the merged trace stage) lets more boxes pass; without it the box tests are the same as well.
-    exact = [i for i, env in enumerate(configs) if env.get("NORI_HIP_SPEC") == "0" or env.get("NORI_HIP_MERGE") == "0" or env["NORI_HIP_PIPELINE"] == "mega"]
-    assert len(exact) == 4
+    # How the steps of a traversal are scheduled changes no ray's sequence of record tests.  Speculative traversal (every
+    # kernel's traversal loop parks a leaf and goes on while its records are tested) lets a few more boxes pass,
+    # depending on the schedule; the records tested are the reference's, to the last one.
     for i, st in enumerate(stats):
         assert st["prims_tested"] == stats[0]["prims_tested"], (i, st["prims_tested"], stats[0]["prims_tested"])
-        if i in exact:
-            assert st["boxes_tested"] == stats[exact[0]]["boxes_tested"], (i, st["boxes_tested"])
-        else:
-            assert st["boxes_tested"] >= stats[exact[0]]["boxes_tested"], (i, st["boxes_tested"])
+    boxes = [st["boxes_tested"] for st in stats]
+    assert max(boxes) <= 1.05 * min(boxes), boxes
     assert stats[0]["camera_samples"] == W * H * spp and stats[0]["iterations"] > 10
+
+
+def test_scene_whose_tree_is_one_leaf_through_every_schedule():
+    """test-furnace.xml: 12 triangles in one leaf, so the root reference is that leaf and no box step ever runs (the
+    speculative trace stage takes the leaf's entry distance from the ray's start, not from a box step).  One pixel, many
+    samples: every schedule tests the same records and gets the furnace's radiance 1 / (1 - albedo)."""
+    films, stats = [], []
+    configs = [dict(NORI_HIP_PIPELINE="wavefront"), dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SPEC="0"),
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_POOL="512", NORI_HIP_THR="3,5,7"), dict(NORI_HIP_PIPELINE="mega")]
+    for env in configs:
+        os.environ.update(env)
+        try:
+            ht = NH.HostScene(os.path.join(SCENES, "tests", "test-furnace.xml"))
+            ctx = ht.preprocess(2)
+        finally:
+            for k in env:
+                del os.environ[k]
+        for rep in range(3):                                   # (lanes take ray after ray: state left by the previous one must not matter)
+            ctx.reset_stats(); ctx.clear_film(); ctx.render(0, 20000)
+            films.append(ctx.read_film()); stats.append(ctx.stats())
+        ht.close()
+    for f, st in zip(films, stats):
+        assert f[..., 3].sum() == 20000.0
+        assert abs(f[..., :3].sum() / (3 * 20000.0) - 2.0) < 0.02            # albedo 0.5, radiance 1
+        assert np.allclose(f, films[0], rtol=2e-4)
+        for k in ("camera_samples", "closest_rays", "prims_tested"):
+            assert st[k] == stats[0][k], (k, st[k], stats[0][k])
+        # (a shadow ray of zero length, maxt < mint, is counted by the single kernel and never staged by the trace stage)
+        assert abs(st["shadow_rays"] - stats[0]["shadow_rays"]) <= 2
 
 
 @pytest.mark.parametrize("name", list(IMAGE_XML))
