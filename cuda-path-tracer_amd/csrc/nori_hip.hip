@@ -478,13 +478,17 @@ __global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsig
 // interleaved share: no shared counter).  Rays reach the lanes through a small pipeline, so that the HBM latency of
 // the pool is paid once per batch and overlaps with traversal instead of stalling every trip:
 //   load     one batch ahead, coalesced, into registers (the wait lands one or more trips later)
-//   stage    the rays that exist (maxt >= mint) are packed into the wave's LDS buffer
+//   stage    when the batch has arrived: the start of every ray's traversal (Trav::begin: adaptive epsilon, reciprocal
+//            direction, root box) with the whole batch busy; rays that do not enter the tree are answered on the spot,
+//            the others are packed into the wave's LDS buffer
 //   hand out a lane whose ray has finished takes the next staged ray (ballot + prefix count)
 // Every trip of the loop the wave decides, from ballots of the lane states, which traversal step is worth issuing:
 //   retire+refill  when at least `thr.z` lanes have finished (or nothing else is left to do)
 //   box_step       when at least `thr.x` lanes stand at an inner node (or no lane stands at a leaf)
-//   prim_step      when at least `thr.y` lanes stand at a leaf record (or the box step did not run)
+//   prim_step      (not SPEC) when at least `thr.y` lanes stand at a leaf record (or the box step did not run)
 //   pop_step       for the lanes that need a stack entry
+//   box_step       a second time when at least `box2_lanes` lanes stand at an inner node again
+//   record step    (SPEC) for the parked leaves, see below
 // The steps are straight-line code.  At least one step runs per trip, so the loop always makes progress; it ends
 // when the wave's batches are used up and every lane has retired its ray.  Results leave through plain stores:
 // the hit record (extend) or the visibility word sh_c.w (shadow).
@@ -494,7 +498,8 @@ __global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsig
 // its ray), so an iteration has one kernel tail instead of two.
 enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // SPEC (speculative traversal): a lane that reaches a leaf parks it (`pend`) and goes on traversing; the record step runs
-// for the parked leaves once thr.y lanes have one (or no lane can traverse), so it runs fuller and less often.  While a
+// for the parked leaves once thr.y lanes have one (default 1: every trip; or no lane can traverse, or the box step did
+// not run), so a ray's record tests no longer hold up its box tests.  While a
 // leaf is parked the lane's box tests use a maxt that its records may yet shrink, which only lets more boxes pass.  The
 // reference tests a leaf's box when it gets to it, after every earlier leaf (src/bvh.cpp:404-463): a lane parks its next
 // leaf only when the parked one is finished, and re-tests the entry distance against maxt at that moment - the same
