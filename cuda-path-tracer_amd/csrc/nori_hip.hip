@@ -286,8 +286,9 @@ struct Pool {
 
 // Counters, one per 256-byte line (see DevStats).  v[0]: slots that hold a live path after the last shade stage.
 #define ND_LINE 64                              /* unsigned ints per 256-byte line */
-struct WfCounters { unsigned int v[2 * ND_LINE]; };
+struct WfCounters { unsigned int v[(2 + 8) * ND_LINE]; };
 #define CN_LIVE(c) ((c)->v[0])
+#define CN_DYN(c, q) ((c)->v[(2 + (q)) * ND_LINE])        /* trace stage: eight cursors into the dynamically handed-out batches */
 
 __global__ void k_pool_init(Pool pool, unsigned int n, WfCounters *cnt) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,7 +299,7 @@ __global__ void k_pool_init(Pool pool, unsigned int n, WfCounters *cnt) {
     }
     if (i == 0) CN_LIVE(cnt) = 0u;
 }
-__global__ void k_iter_begin(WfCounters *cnt) { CN_LIVE(cnt) = 0u; }
+__global__ void k_iter_begin(WfCounters *cnt) { CN_LIVE(cnt) = 0u; for (int q = 0; q < 8; ++q) CN_DYN(cnt, q) = 0u; }
 
 // Once the work counter is exhausted the live paths thin out by about a quarter per bounce, while every stage still
 // sweeps the whole pool.  When fewer than half of the slots are live the host has them packed into the front of a
@@ -505,7 +506,7 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // leaf only when the parked one is finished, and re-tests the entry distance against maxt at that moment - the same
 // test at the same point of the depth-first order, so the same records are tested with the same maxt, in the same order.
 template <int KIND, bool PROF, bool SPEC = false>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
     extern __shared__ float4 dyn_lds[];
     const unsigned int nw = blockDim.x >> 6;
@@ -517,7 +518,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     constexpr bool ANY = (KIND == TK_SHADOW);
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, nb_pool = (n_slots + 63u) >> 6, n_batches = (KIND == TK_BOTH) ? 2u * nb_pool : nb_pool;
-    unsigned int b_next = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform: next batch to load
+    unsigned int b_next = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform: next batch of the static share
+    // The last dyn_pct percent of the rounds are not dealt statically: their batches [n_static, n_batches) sit in eight
+    // queues (one cursor each, on its own cache line) and a wave that has finished its share takes from its queue, then
+    // from the others, so that the waves end together.
+    const unsigned int dyn_pct = (box2_lanes >> 8) & 0xffu;
+    // (a wave tries dyn_tries of the queues, its own first; every queue is some block's own when the grid has 8 blocks)
+    const unsigned int dyn_tries = (box2_lanes >> 16) & 0xfu;
+    const unsigned int n_static = (dyn_pct && gridDim.x >= 8u) ? ((n_batches / n_waves) * (100u - dyn_pct) / 100u) * n_waves : n_batches;
+    const unsigned int per_q = (n_batches - n_static + 7u) >> 3;
+    unsigned int dq = (n_static < n_batches) ? 8u - dyn_tries : 8u;   // wave-uniform: 8 - the queues this wave may still try (its own first)
+    bool dyn_asked = false; unsigned int dyn_idx = 0u;                   // a cursor has been asked for; lane 0 holds the answer
     bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     for (;;) {
         // (wave-uniform by construction; said explicitly so that they live in scalar registers and branch on SCC)
         s_pos = __builtin_amdgcn_readfirstlane(s_pos); s_n = __builtin_amdgcn_readfirstlane(s_n);
-        b_next = __builtin_amdgcn_readfirstlane(b_next); l_base = __builtin_amdgcn_readfirstlane(l_base);
+        b_next = __builtin_amdgcn_readfirstlane(b_next); l_base = __builtin_amdgcn_readfirstlane(l_base); dq = __builtin_amdgcn_readfirstlane(dq);
         // ---- feed the staging pipeline
         if (s_pos >= s_n && loading) {
             // The batch has arrived.  The start of a traversal (adaptive epsilon, reciprocal direction, root box:
@@ -563,13 +574,28 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
             }
             s_n = (unsigned int) __popcll(m); s_pos = 0; loading = false;
         }
-        if (!loading && b_next < n_batches) {
-            l_any = (KIND == TK_BOTH) ? (b_next < nb_pool) : ANY;
-            l_base = ((KIND == TK_BOTH && !l_any) ? b_next - nb_pool : b_next) << 6;
+        unsigned int b_take = 0xffffffffu;                                   // wave-uniform: the batch to load now
+        if (!loading) {
+            if (b_next < n_static) { b_take = b_next; b_next += n_waves; }
+            else if (dyn_asked) {
+                // the cursor asked for in the previous trip (its round trip overlapped with that trip's steps)
+                const unsigned int qq = (blockIdx.x + dq + dyn_tries) & 7u, idx = __builtin_amdgcn_readfirstlane(dyn_idx);
+                const unsigned int b = n_static + qq * per_q + idx;
+                if (idx < per_q && b < n_batches) b_take = b; else dq++;
+                dyn_asked = false;
+            }
+            if (b_take == 0xffffffffu && b_next >= n_static && dq < 8u) {
+                if (lane == 0) dyn_idx = atomicAdd(&CN_DYN(cnt, (blockIdx.x + dq + dyn_tries) & 7u), 1u);
+                dyn_asked = true;
+            }
+        }
+        if (b_take != 0xffffffffu) {
+            l_any = (KIND == TK_BOTH) ? (b_take < nb_pool) : ANY;
+            l_base = ((KIND == TK_BOTH && !l_any) ? b_take - nb_pool : b_take) << 6;
             const unsigned int sl = l_base + lane;
             if (sl < n_slots) { lo4 = l_any ? pool.sh_o[sl] : pool.ray_o[sl]; ld4 = l_any ? pool.sh_d[sl] : pool.ray_d[sl]; }
             else { lo4 = make_float4(0.f, 0.f, 0.f, 0.f); ld4 = make_float4(0.f, 0.f, 0.f, -1.f); }
-            loading = true; b_next += n_waves;
+            loading = true;
         }
         // ---- retire finished rays, hand out staged ones
         const unsigned long long fin = __ballot(tv.done() && (!SPEC || pend == 0u));   // finished or never started
@@ -594,7 +620,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
                 }
                 s_pos += (unsigned int) __popcll(fin);
             }
-            if (!loading && s_pos >= s_n && b_next >= n_batches && __ballot(have) == 0ull) break;   // nothing staged, loading or in flight
+            if (!loading && s_pos >= s_n && b_next >= n_static && dq >= 8u && !dyn_asked && __ballot(have) == 0ull) break;   // nothing staged, loading or in flight
         }
         // ---- traversal steps
         const unsigned long long m_in = __ballot(tv.at_inner());
@@ -620,9 +646,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
         if (tv.at_pop()) tv.pop_step(stk);
         // a second box step for the lanes that stand at an inner node again (popped one, or descended into one), when enough do
-        if (box2_lanes) {
+        if (box2_lanes & 0xffu) {
             const unsigned long long m_in2 = __ballot(tv.at_inner());
-            if ((unsigned int) __popcll(m_in2) >= box2_lanes) {
+            if ((unsigned int) __popcll(m_in2) >= (box2_lanes & 0xffu)) {
                 if (PROF) { pf[1]++; pf[2] += __popcll(m_in2); }
                 n_boxes += 2u * (unsigned int) __popcll(m_in2);
                 const bool ord = ((KIND == TK_BOTH) ? any : ANY) || sc.ordered != 0;
@@ -916,6 +942,8 @@ struct NoriHipContext {
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
     bool spec = true;                 // NORI_HIP_SPEC=0: no speculative traversal in the merged trace stage
+    int dyn_tries = 3;                // NORI_HIP_DYN_TRIES: queues a finishing wave tries (1..8)
+    int dyn_pct = 15;                 // NORI_HIP_DYN: percent of the trace stage's rounds of batches that are handed out dynamically at the end
     int box2 = 36;                    // NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
@@ -967,6 +995,8 @@ int nori_hip_create(int device, NoriHipContext **out) {
     if (const char *e = getenv("NORI_HIP_LBVH_BIG")) { float v = (float) atof(e); if (v >= 0.f) c->lbvh_big = v; }
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0;
+    if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
+    if (const char *e = getenv("NORI_HIP_DYN")) { int v = atoi(e); if (v >= 0 && v <= 90) c->dyn_pct = v; }
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
     if (const char *e = getenv("NORI_HIP_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
@@ -1296,7 +1326,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (6 * 4 / trace_nw)));     // more workgroups than that run in rounds
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
-    const unsigned int trace_box2 = (unsigned int) ctx->box2;
+    const unsigned int trace_box2 = (unsigned int) ctx->box2 | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16);
     const size_t trace_lds = trace_fixed;
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
@@ -1330,12 +1360,14 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
                 else { hipEvent_t a_, b_; HIPCHK(hipEventCreate(&a_)); HIPCHK(hipEventCreate(&b_)); ctx->ext_ev.push_back(a_); ctx->ext_ev.push_back(b_); }
             }
-#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2)
+// (the cursors of the dynamically handed-out batches are reset once per iteration, by k_iter_begin: only the merged
+            // stage, one launch per iteration, uses them)
+#define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, ((K) == TK_BOTH ? trace_box2 : (trace_box2 & 0xffu)), c)
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
                 if (ctx->spec) {
-                    if (ctx->profile) hipLaunchKernelGGL((k_trace_pool<TK_BOTH, true, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2);
-                    else hipLaunchKernelGGL((k_trace_pool<TK_BOTH, false, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2);
+                    if (ctx->profile) hipLaunchKernelGGL((k_trace_pool<TK_BOTH, true, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
+                    else hipLaunchKernelGGL((k_trace_pool<TK_BOTH, false, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
                 } else if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used + 1], ctx->stream));
             } else {

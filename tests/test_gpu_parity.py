@@ -180,7 +180,10 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
                dict(NORI_HIP_PIPELINE="mega", NORI_HIP_MEGA_WAVES="6", NORI_HIP_LDS="20480"),
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SPEC="1"),                                  # speculative traversal
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SPEC="1", NORI_HIP_THR="1,40,8", NORI_HIP_POOL="4096"),
-               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_THR="64,64,64", NORI_HIP_BOX2="64", NORI_HIP_POOL="4096")]   # every step waits for a full wave
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_THR="64,64,64", NORI_HIP_BOX2="64", NORI_HIP_POOL="4096"),   # every step waits for a full wave
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_DYN="0"),                                  # all batches dealt statically
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_DYN="90", NORI_HIP_DYN_TRIES="1", NORI_HIP_POOL="70000"),   # nearly all from the queues, own queue only
+               dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_DYN="50", NORI_HIP_DYN_TRIES="8", NORI_HIP_POOL="1000")]    # a grid of fewer than 8 workgroups
     for env in configs:
         os.environ.update(env)
         try:
