@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsig
     shade_body<true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats); }
 
 // Trace stage: persistent waves over the pool.  Wave w of W takes the 64-slot batches w, w+W, w+2W, ... (a static,
-// interleaved share: no shared counter).  Rays reach the lanes through a small pipeline, so that the HBM latency of
+// interleaved share: no shared counter) for the first 85 % of the rounds; the rest comes from eight queues, see below.  Rays reach the lanes through a small pipeline, so that the HBM latency of
 // the pool is paid once per batch and overlaps with traversal instead of stalling every trip:
 //   load     one batch ahead, coalesced, into registers (the wait lands one or more trips later)
 //   stage    when the batch has arrived: the start of every ray's traversal (Trav::begin: adaptive epsilon, reciprocal
