@@ -349,7 +349,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
     const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
     const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
-    unsigned int n_invalid = 0;
+    unsigned int n_invalid = 0, n_degenerate = 0;
     Counters probe_ctr = {0, 0, 0, 0};                                      // EXT: probe rays traced while shading
     const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
     if (threadIdx.x == 0) { l_regen = 0u; l_keep = 0u; }
@@ -376,10 +376,18 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                     shade_hit<EXT>(sc, ps, rng, hit, so, EXT ? &probe_ctr : nullptr);
                     flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
                     if (so.has_shadow) {
-                        new_shadow = true; flags |= PF_SHADOW;
-                        pool.sh_o[slot] = make_float4(so.shadow.o.x, so.shadow.o.y, so.shadow.o.z, so.shadow.mint);
-                        pool.sh_d[slot] = make_float4(so.shadow.d.x, so.shadow.d.y, so.shadow.d.z, so.shadow.maxt);
-                        pool.sh_c[slot] = make_float4(so.contrib.x, so.contrib.y, so.contrib.z, 0.f);
+                        flags |= PF_SHADOW;
+                        // A light sample closer than 2e-3 gives a shadow ray with maxt < mint.  BVH::rayIntersect returns false for
+                        // it without looking at the tree (src/bvh.cpp:414), i.e. unoccluded; in the pool maxt < mint marks "no ray",
+                        // so the answer is written here and the trace stage never sees the ray (counted here for the statistics).
+                        const bool degenerate = so.shadow.maxt < so.shadow.mint;
+                        if (degenerate) n_degenerate++;
+                        else {
+                            new_shadow = true;
+                            pool.sh_o[slot] = make_float4(so.shadow.o.x, so.shadow.o.y, so.shadow.o.z, so.shadow.mint);
+                            pool.sh_d[slot] = make_float4(so.shadow.d.x, so.shadow.d.y, so.shadow.d.z, so.shadow.maxt);
+                        }
+                        pool.sh_c[slot] = make_float4(so.contrib.x, so.contrib.y, so.contrib.z, degenerate ? 1.0f : 0.f);
                     }
                     if (!so.end) {
                         ended = false;
@@ -452,9 +460,9 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
             pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
         }
     }
-    unsigned long long v0 = n_samples, v1 = n_invalid;
-    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); }
-    if (lane == 0 && (v0 | v1)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); }
+    unsigned long long v0 = n_samples, v1 = n_invalid, v2 = n_degenerate;
+    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); v2 += __shfl_down(v2, off, 64); }
+    if (lane == 0 && (v0 | v1 | v2)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); if (v2) atomicAdd(&st->shadow, v2); }
     if (EXT) {
         unsigned long long w[3] = {probe_ctr.closest, probe_ctr.nodes, probe_ctr.prims};
         for (int k = 0; k < 3; ++k) for (int off = 32; off > 0; off >>= 1) w[k] += __shfl_down(w[k], off, 64);
@@ -925,6 +933,7 @@ struct NoriHipContext {
     size_t lds_bytes = 65536;         // LDS a workgroup may use (sharedMemPerBlockOptin)
     // wavefront pipeline
     unsigned int pool_slots = 0; Pool pool, pool_b; void *pool_mem = nullptr;     // pool_b: half the slots, for the compaction of the tail
+    unsigned int pool_alloc = 0;      // slots the allocated pool holds
     bool compact = true;              // NORI_HIP_COMPACT=0: never pack the pool (the tail then sweeps dead slots until k_finish takes over)
     unsigned int *d_qlive = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -941,6 +950,7 @@ struct NoriHipContext {
     bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
+    size_t trace_lds = 0;             // dynamic LDS of a trace-stage workgroup (set once, with the kernels' attribute, in nori_hip_create)
     bool spec = true;                 // NORI_HIP_SPEC=0: no speculative traversal in the merged trace stage
     int dyn_tries = 3;                // NORI_HIP_DYN_TRIES: queues a finishing wave tries (1..8)
     int dyn_pct = 15;                 // NORI_HIP_DYN: percent of the trace stage's rounds of batches that are handed out dynamically at the end
@@ -973,14 +983,24 @@ extern "C" {
 
 const char *nori_hip_last_error(void) { return g_err.c_str(); }
 
+static int create_impl(NoriHipContext *c, int device);
+
 int nori_hip_create(int device, NoriHipContext **out) {
     if (!out) return fail(NORI_HIP_EINVAL, "out is null");
+    *out = nullptr;
     int count = 0;
     HIPCHK(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) return fail(NORI_HIP_EDEVICE, "no such HIP device " + std::to_string(device));
     HIPCHK(hipSetDevice(device));
     NoriHipContext *c = new NoriHipContext();
     c->device = device;
+    const int rc = create_impl(c, device);
+    if (rc != NORI_HIP_OK) { const std::string why = g_err; nori_hip_destroy(c); g_err = why; return rc; }     // nothing half-built is left behind
+    *out = c;
+    return NORI_HIP_OK;
+}
+
+static int create_impl(NoriHipContext *c, int device) {
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device));
     c->n_cus = prop.multiProcessorCount;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) c->lds_bytes = (size_t) v; }
@@ -1017,22 +1037,33 @@ int nori_hip_create(int device, NoriHipContext **out) {
     HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
     HIPCHK(hipHostMalloc((void **) &c->h_ring, 4 * sizeof(unsigned int), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
-    *out = c;
+    // dynamic LDS of the trace stages: stacks + staged rays (origin, direction, reciprocal direction, slot) of the workgroup's waves
+    c->trace_lds = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH * 64 * 8 + 64 * 52);
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
     return NORI_HIP_OK;
 }
 
 int nori_hip_destroy(NoriHipContext *ctx) {
     if (!ctx) return NORI_HIP_OK;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
     hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
     hipFree(ctx->d_qlive); hipFree(ctx->d_filt);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     for (hipEvent_t e : ctx->ext_ev) hipEventDestroy(e);
-    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
-    hipStreamDestroy(ctx->stream);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    (void) hipGetLastError();
     delete ctx;
     return NORI_HIP_OK;
 }
@@ -1044,6 +1075,8 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     if (d->n_shapes == 0 || !d->shapes) return fail(NORI_HIP_EINVAL, "scene has no shapes");
     if (!device_build && d->n_nodes > 0 && !d->nodes) return fail(NORI_HIP_EINVAL, "nodes is null");
     if (d->camera.width <= 0 || d->camera.height <= 0) return fail(NORI_HIP_EINVAL, "bad camera size");
+    if (d->camera.width > 65535 || d->camera.height > 65535) return fail(NORI_HIP_EINVAL, "camera size above 65535 (the path pool packs a pixel into 2 x 16 bits)");
+    if (d->n_textures && (!d->textures || !d->tex_data)) return fail(NORI_HIP_EINVAL, "textures is null");
     // validate every index the kernels will follow: a bad table must be rejected here, not fault on the GPU
     auto ref_ok = [&](uint32_t r) {
         if (r == NORI_HIP_NO_CHILD) return true;
@@ -1070,7 +1103,6 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         if (s.normal_tex && d->textures[s.normal_tex - 1].kind == NORI_HIP_TEX_COLOR) return fail(NORI_HIP_EINVAL, "normal modifier is a colour image");
         if (s.albedo_tex || s.normal_tex) ext = true;
     }
-    if (d->n_textures && (!d->textures || !d->tex_data)) return fail(NORI_HIP_EINVAL, "textures is null");
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const NoriHipTexture &t = d->textures[i];
         if (t.kind > NORI_HIP_TEX_NORMAL || t.lookup > NORI_HIP_LOOKUP_BILINEAR) return fail(NORI_HIP_EINVAL, "unknown texture kind or lookup");
@@ -1298,20 +1330,27 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
         return NORI_HIP_OK;
     }
     // ---- wavefront stages over a pool of path slots
+    // The pool is sized for the call (a quarter of its paths, between 1 M and 8 M slots, or NORI_HIP_POOL) and allocated when a
+    // call needs more slots than the context holds; pool, half-size pool and live list are committed to the context together.
     const unsigned int pool_cap = ctx->pool_slots ? ctx->pool_slots : (1u << 23);
-    if (!ctx->pool_mem) {
-        const size_t P = pool_cap, PB = ((P / 2 + 63) / 64) * 64 + 64;
-        HIPCHK(hipMalloc(&ctx->pool_mem, (P + PB) * 10 * sizeof(float4)));
+    unsigned int P = pool_cap;
+    if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, (job.total / 4 + 65535) & ~65535ull));
+    if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
+    if (!ctx->pool_mem || ctx->pool_alloc < P) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->pool_mem); hipFree(ctx->d_qlive); ctx->pool_mem = nullptr; ctx->d_qlive = nullptr; ctx->pool_alloc = 0;
+        const size_t PA = ((size_t) P + 63) / 64 * 64, PB = ((PA / 2 + 63) / 64) * 64 + 64;
+        DevBufs guard; float4 *mem = nullptr; unsigned int *ql = nullptr;
+        HIPCHK(guard.get(mem, (PA + PB) * 10 * sizeof(float4)));
+        HIPCHK(guard.get(ql, PA * 4));
+        guard.owned.clear();                                                   // both succeeded: the context owns them now
+        ctx->pool_mem = mem; ctx->d_qlive = ql; ctx->pool_alloc = (unsigned int) PA;
         auto carve = [](Pool &pl, float4 *base, size_t n) {
             pl.ray_o = base; pl.ray_d = base + n; pl.hit = (uint4 *) (base + 2 * n); pl.thr = base + 3 * n; pl.li = base + 4 * n;
             pl.rng = (uint4 *) (base + 5 * n); pl.pix = base + 6 * n; pl.sh_o = base + 7 * n; pl.sh_d = base + 8 * n; pl.sh_c = base + 9 * n;
         };
-        carve(ctx->pool, (float4 *) ctx->pool_mem, P); carve(ctx->pool_b, (float4 *) ctx->pool_mem + 10 * P, PB);
-        HIPCHK(hipMalloc((void **) &ctx->d_qlive, P * 4));
+        carve(ctx->pool, mem, PA); carve(ctx->pool_b, mem + 10 * PA, PB);
     }
-    unsigned int P = pool_cap;
-    if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, (job.total / 4 + 65535) & ~65535ull));
-    if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     WfCounters *c = ctx->d_cnt;
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
@@ -1327,15 +1366,7 @@ int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
     const unsigned int trace_box2 = (unsigned int) ctx->box2 | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16);
-    const size_t trace_lds = trace_fixed;
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trace_lds));
+    const size_t trace_lds = ctx->trace_lds;
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
     unsigned trace_blocks = 1, shade_blocks = 1; size_t shade_lds = 0;
     auto shade_run = [](unsigned int slots, unsigned int blocks) { return (((slots + blocks - 1) / blocks) + 255u) & ~255u; };   // = per_block in shade_body
@@ -1447,12 +1478,11 @@ int nori_hip_read_bitmap(NoriHipContext *ctx, float *rgb) {
     SCENECHK(ctx);
     if (!rgb) return fail(NORI_HIP_EINVAL, "null buffer");
     const int W = ctx->sc.cam.width, H = ctx->sc.cam.height;
-    float *d = nullptr; HIPCHK(hipMalloc((void **) &d, (size_t) W * H * 12));
+    DevBufs bufs; float *d = nullptr; HIPCHK(bufs.get(d, (size_t) W * H * 12));
     hipLaunchKernelGGL(k_bitmap, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rgb, d, (size_t) W * H * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(d);
     return NORI_HIP_OK;
 }
 

@@ -233,10 +233,10 @@ def test_scene_whose_tree_is_one_leaf_through_every_schedule():
         assert f[..., 3].sum() == 20000.0
         assert abs(f[..., :3].sum() / (3 * 20000.0) - 2.0) < 0.02            # albedo 0.5, radiance 1
         assert np.allclose(f, films[0], rtol=2e-4)
-        for k in ("camera_samples", "closest_rays", "prims_tested"):
+        # (shadow_rays included: a shadow ray of zero length, maxt < mint, is unoccluded without a traversal — src/bvh.cpp:414 —
+        # in every pipeline, counted, and its NEE term added)
+        for k in ("camera_samples", "closest_rays", "shadow_rays", "prims_tested"):
             assert st[k] == stats[0][k], (k, st[k], stats[0][k])
-        # (a shadow ray of zero length, maxt < mint, is counted by the single kernel and never staged by the trace stage)
-        assert abs(st["shadow_rays"] - stats[0]["shadow_rays"]) <= 2
 
 
 @pytest.mark.parametrize("name", list(IMAGE_XML))
