@@ -901,6 +901,17 @@ __global__ __launch_bounds__(NLM_BW * NLM_BH) void k_nlmeans_sep(const float *im
     if (inside) { float *o = out + ((size_t) y * w + x) * 3; o[0] = a0 / wsum; o[1] = a1 / wsum; o[2] = a2 / wsum; }
 }
 
+// ImageBlock::toBitmap followed by Color3f::toSRGB in one pass: what k_bitmap + k_srgb leave in their second buffer
+__global__ void k_bitmap_srgb(const float4 *film, int w, int h, int border, int cols, float *srgb) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float4 c = film[(size_t) (y + border) * cols + (x + border)];
+    float *o = srgb + ((size_t) y * w + x) * 3;
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (c.w != 0) { r = c.x / c.w; g = c.y / c.w; b = c.z / c.w; }
+    o[0] = to_srgb(r); o[1] = to_srgb(g); o[2] = to_srgb(b);
+}
+
 template <typename T> int upload(T *&dptr, const T *src, size_t n) {
     dptr = nullptr;
     if (n == 0) return NORI_HIP_OK;
@@ -910,6 +921,10 @@ template <typename T> int upload(T *&dptr, const T *src, size_t n) {
 }
 
 } // namespace
+
+// Scratch of nori_hip_filter_noalloc: the sRGB-encoded bitmap the NL-means kernel reads.  One copy per GPU, held until the
+// process ends; its device address is taken per device in nori_hip_create (hipGetSymbolAddress) and kept in the context.
+static __device__ __align__(256) float scratch[(size_t) NORI_HIP_NOALLOC_MAX_PIXELS * 3];
 
 struct NoriHipContext {
     int device = 0;
@@ -950,6 +965,7 @@ struct NoriHipContext {
     bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
+    float *scratch_ptr = nullptr;     // this device's copy of `scratch` (nori_hip_filter_noalloc)
     size_t trace_lds = 0;             // dynamic LDS of a trace-stage workgroup (set once, with the kernels' attribute, in nori_hip_create)
     bool spec = true;                 // NORI_HIP_SPEC=0: no speculative traversal in the merged trace stage
     int dyn_tries = 3;                // NORI_HIP_DYN_TRIES: queues a finishing wave tries (1..8)
@@ -1037,6 +1053,9 @@ static int create_impl(NoriHipContext *c, int device) {
     HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
     HIPCHK(hipHostMalloc((void **) &c->h_ring, 4 * sizeof(unsigned int), hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
+    // the device address of this GPU's copy of the no-allocation scratch array (the array's name is a host-side stand-in)
+    HIPCHK(hipGetSymbolAddress((void **) &c->scratch_ptr, HIP_SYMBOL(scratch)));
+    if (!c->scratch_ptr) return fail(NORI_HIP_EDEVICE, "hipGetSymbolAddress(scratch) returned a null address");
     // dynamic LDS of the trace stages: stacks + staged rays (origin, direction, reciprocal direction, slot) of the workgroup's waves
     c->trace_lds = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH * 64 * 8 + 64 * 52);
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
@@ -1515,6 +1534,28 @@ int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, flo
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NORI_HIP_OK;
+}
+
+// nori_hip_filter for callers that cannot allocate: no hipMalloc / hipFree, no copy to the host, no synchronisation.  The
+// intermediate image lives in this GPU's `scratch` array (ctx->scratch_ptr), every pixel of which is rewritten before it is
+// read, so nothing needs clearing between calls; calls that overlap on one GPU (two contexts, two threads) race on it.
+int nori_hip_filter_noalloc(NoriHipContext *ctx, int r, int f, float sigma, float h, float *d_rgb_srgb_out) {
+    SCENECHK(ctx);
+    if (!d_rgb_srgb_out) return fail(NORI_HIP_EINVAL, "null buffer");
+    if (r < 0 || f < 0 || !(sigma > 0) || !(h > 0)) return fail(NORI_HIP_EINVAL, "bad filter parameters");
+    const int W = ctx->sc.cam.width, H = ctx->sc.cam.height, R = r + f;
+    if ((size_t) W * (size_t) H > (size_t) NORI_HIP_NOALLOC_MAX_PIXELS)
+        return fail(NORI_HIP_EINVAL, "nori_hip_filter_noalloc: image of " + std::to_string((size_t) W * H) + " pixels exceeds NORI_HIP_NOALLOC_MAX_PIXELS (" +
+                    std::to_string((size_t) NORI_HIP_NOALLOC_MAX_PIXELS) + "); use nori_hip_filter");
+    const size_t lds_sep = ((size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 + (size_t) (NLM_BW + 2 * f) * (NLM_BH + 2 * f) + (size_t) (NLM_BH + 2 * f) * NLM_BW + (size_t) (2 * f + 1)) * sizeof(float);
+    if (lds_sep > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile");
+    float *d_srgb = ctx->scratch_ptr;
+    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans_sep, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_sep));
+    hipLaunchKernelGGL(k_bitmap_srgb, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d_srgb);
+    hipLaunchKernelGGL(k_nlmeans_sep, dim3((W + NLM_BW - 1) / NLM_BW, (H + NLM_BH - 1) / NLM_BH), dim3(NLM_BW, NLM_BH), lds_sep, ctx->stream,
+                       (const float *) d_srgb, d_rgb_srgb_out, W, H, r, f, sigma, h);
+    HIPCHK(hipGetLastError());
     return NORI_HIP_OK;
 }
 

@@ -90,6 +90,7 @@ def hip_lib():
         L.nori_hip_film_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
         L.nori_hip_read_bitmap.argtypes = [vp, vp]
         L.nori_hip_filter.argtypes = [vp, i32, i32, C.c_float, C.c_float, vp]
+        L.nori_hip_filter_noalloc.argtypes = [vp, i32, i32, C.c_float, C.c_float, vp]
         L.nori_hip_stats.argtypes = [vp, C.POINTER(Stats)]
         L.nori_hip_reset_stats.argtypes = [vp]
         L.nori_hip_stream.argtypes = [vp, C.POINTER(vp)]
@@ -251,6 +252,10 @@ class Context:
         out = np.zeros((rows - 2 * b, cols - 2 * b, 3), np.float32)
         _hchk(self.L.nori_hip_filter(self.h, r, f, sigma, h, _vp(out)))
         return out
+
+    def filter_noalloc(self, d_out, r=3, f=10, sigma=0.5, h=0.002):
+        """nori_hip_filter_noalloc: d_out is a device address (height x width x 3 floats); asynchronous on the context's stream"""
+        _hchk(self.L.nori_hip_filter_noalloc(self.h, r, f, sigma, h, C.c_void_p(d_out)))
 
     def stats(self):
         s = Stats()

@@ -245,6 +245,16 @@ int nori_hip_read_bitmap(NoriHipContext *ctx, float *rgb);
  * Output: height x width x 3 floats, sRGB-encoded (what the fork stores in `image`). */
 int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, float *rgb_srgb_out);
 
+/* nori_hip_filter for callers that cannot allocate (code under HIP graph capture, tight progressive-display loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  The same kernels and the same result as nori_hip_filter (its
+ * default, separable form), but: the output goes to a DEVICE buffer of the caller (height x width x 3 floats), the call
+ * neither allocates nor frees nor synchronises (it is asynchronous on the context's stream), and the intermediate sRGB
+ * bitmap lives in a static device array of NORI_HIP_NOALLOC_MAX_PIXELS x 3 floats (24.9 MB, one copy per GPU, held until
+ * the process ends).  Images with more pixels are rejected with NORI_HIP_EINVAL.  All calls on one GPU share that array:
+ * calls that overlap on one GPU (two contexts, two threads) race. */
+#define NORI_HIP_NOALLOC_MAX_PIXELS 2073600   /* 1920 x 1080 */
+int nori_hip_filter_noalloc(NoriHipContext *ctx, int r, int f, float sigma, float h, float *d_rgb_srgb_out);
+
 int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out);
 int nori_hip_reset_stats(NoriHipContext *ctx);
 /* stream the context launches on (hipStream_t as void*), for callers that time or order work around it */
