@@ -7,10 +7,16 @@ renders its own spp slice of the same image (weak scaling: per-GPU work is fixed
 over ranks with one RCCL all-reduce per step, inside the timed region.
 
 Workloads (BASELINE.json configs):
-  table  scenes/table/table_path_mis_microfacet.xml 800x600, 256 spp   (configs[1]: the single-GPU configuration; default)
+  c4     synthetic 10.0 M-triangle height field under area lights, 1024x1024, 16 spp (configs[3]; default: BASELINE's metric is
+         quoted on "cbox & 10M-tri", and this is the one whose working set (1.1 GB of nodes and records) does not fit the caches,
+         so the HBM roofline of the traversal kernel is physical on it)
   cbox   scenes/cbox/cbox_path_mis.xml at 512x512, 64 spp      (configs[0], the reference's CPU-runnable case)
+  table  scenes/table/table_path_mis_microfacet.xml 800x600, 256 spp   (configs[1])
   dragon scenes/proj/dragon-diffuse.xml 800x600, 64 spp        (mid-size: 105 k triangles, depth-26 tree)
-  c4     synthetic ~10M-triangle height field under area lights, 1024x1024, 16 spp (config 4)
+  proj / subsurface   scenes/proj (configs[2])
+  c5     cbox 3840x2160 split by spp, RCCL reduce, filter pass (configs[4]; --spp sets the per-GPU sample count)
+--bvh host|device: the reference's SAH tree in the reference's order (bit-exact hit ids on ties; built on the host) or the tree
+built on the GPU (default for c4, whose host build takes 14 s).
 """
 import argparse
 import json
@@ -25,44 +31,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-
-
-def make_c4(n_side, width, height, spp):
-    """Synthetic BVH-traversal stress scene: a jittered, displaced n_side x n_side-quad height field
-    (2*n_side^2 triangles; 2236 -> 10.0 M) inside cbox-like walls under four quad lights, all diffuse 0.5."""
-    import nori_hip as NH
-    import oracle_lib as O
-    g = n_side + 1
-    f = O.pcg32_floats(1234, 1, 3 * g * g).reshape(g, g, 3)          # vertices from pcg32.seed(1234, 1)
-    step = 2.0 / n_side
-    xs, zs = np.meshgrid(np.linspace(-1, 1, g, dtype=np.float32), np.linspace(-1, 1, g, dtype=np.float32))
-    jit = (f[:, :, 0:2] - 0.5) * 0.6 * step
-    jit[0, :, :] = 0; jit[-1, :, :] = 0; jit[:, 0, :] = 0; jit[:, -1, :] = 0
-    V = np.stack([xs + jit[:, :, 0], 0.2 * f[:, :, 2], zs + jit[:, :, 1]], 2).reshape(-1, 3).astype(np.float32)
-    i = np.arange(g * g, dtype=np.uint32).reshape(g, g)
-    a, b, c, d = i[:-1, :-1].ravel(), i[:-1, 1:].ravel(), i[1:, 1:].ravel(), i[1:, :-1].ravel()
-    F = np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)]).astype(np.uint32)
-    sb = NH.SceneBuilder()
-    sb.add_mesh("heightfield", V, F, color=(0.5, 0.5, 0.5))
-    # closed box: back, left, right, ceiling, front (the floor is the height field)
-    def quad(p):
-        return np.array(p, np.float32), np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
-    walls = {
-        "back": [[-1, 0, -1], [1, 0, -1], [1, 2, -1], [-1, 2, -1]],
-        "front": [[1, 0, 1], [-1, 0, 1], [-1, 2, 1], [1, 2, 1]],
-        "left": [[-1, 0, 1], [-1, 0, -1], [-1, 2, -1], [-1, 2, 1]],
-        "right": [[1, 0, -1], [1, 0, 1], [1, 2, 1], [1, 2, -1]],
-        "ceil": [[-1, 2, -1], [1, 2, -1], [1, 2, 1], [-1, 2, 1]],
-    }
-    for k, p in walls.items():
-        v, fi = quad(p)
-        sb.add_mesh(k, v, fi, color=(0.5, 0.5, 0.5))
-    for li, (cx, cz) in enumerate([(-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5)]):
-        s = 0.15
-        v, fi = quad([[cx - s, 1.98, cz - s], [cx - s, 1.98, cz + s], [cx + s, 1.98, cz + s], [cx + s, 1.98, cz - s]])
-        sb.add_mesh("light%d" % li, v, fi, color=(0.5, 0.5, 0.5), radiance=(15, 15, 15))
-    sb.set_camera((0.0, 1.0, 0.95), (0.0, 0.1, -0.3), (0, 1, 0), 60.0, width, height)
-    return sb.finish(spp=spp)
 
 
 WORKLOADS = {
@@ -80,7 +48,12 @@ WORKLOADS = {
                        name="proj cbox_subsurface path_mis 800x600 50spp as shipped (two subsurface shapes, probe rays)"),
     "c4": dict(xml=None, width=1024, height=1024, spp=16, n_side=2236,
                name="synthetic 10M-triangle height field under 4 area lights 1024x1024 16spp (BASELINE config 4)"),
+    # BASELINE config 5: 16384 spp over 8 GPUs = 2048 spp per GPU; the default here is a scaled per-GPU count (same code path) so
+    # that a default run finishes in seconds, --spp 2048 is the configuration as stated
+    "c5": dict(xml="scenes/cbox/cbox_path_mis.xml", width=3840, height=2160, spp=32, filter=True,
+               name="cbox path_mis 3840x2160 split by spp, RCCL film reduce, NL-means filter pass (BASELINE config 5; spp per GPU scaled from 2048)"),
 }
+FILTER_PARAMS = dict(r=3, f=10, sigma=0.5, h=0.002)      # the CUDA fork's scene defaults (cuda/nori/scene.cpp:28-32)
 
 
 def film_tensor(ctx, torch):
@@ -92,45 +65,71 @@ def film_tensor(ctx, torch):
     return torch.as_tensor(_Film(), device="cuda")
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(w, args):
     """The oracle (CPU restatement, pinned bit-for-bit against the reference's sources) timed on this host: all threads the
     box gives us on a bounded sample of the workload, one thread on a smaller one, BVH build apart."""
     import oracle_lib as O
     threads = min(16, os.cpu_count() or 1)
     if w["xml"] is None:
-        return None
-    spp = args.cpu_spp
+        # C4: the reference's ingest is text OBJ + a one-thread SAH build, minutes for 10 M triangles.  The bounded sample is
+        # the same generator at a tenth of the triangles (same box, lights, camera), written as OBJ + XML and loaded by the
+        # oracle as the reference would load it, rendered at reduced size.  Fewer triangles make the CPU's rays cheaper
+        # (a shallower tree), so this baseline errs in the CPU's favour.
+        import tempfile
+        from nori_hip import synthetic
+        side, cw, ch, spp = args.cpu_c4_side, 256, 256, args.cpu_spp or 16
+        with tempfile.TemporaryDirectory() as d:
+            t0 = time.time()
+            xml = synthetic.write_c4(d, side, cw, ch, spp)
+            write_s = time.time() - t0
+            t0 = time.time()
+            o = O.OracleScene(xml, cw, ch, spp)
+            load_s = time.time() - t0
+        sec, st = o.render(0, spp, mode=0, threads=threads)
+        n = cw * ch * spp
+        return {"value": round(n / sec / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                "sample": "the same generator at n_side=%d (%d triangles instead of %d), %dx%d, %d spp (%.1f s), reference block-stream mode" % (
+                    side, o.info()["prims"], 2 * w["n_side"] ** 2 + 18, cw, ch, spp, sec),
+                "mrays_per_s": round((st["closest"] + st["shadow"]) / sec / 1e6, 4),
+                "boxes_tested_per_ray": round(st["nodes"] / max(1, st["closest"] + st["shadow"]), 1),
+                "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "obj_write_s": round(write_s, 2), "scene_load_and_bvh_build_s": round(load_s, 2)}
+    spp = args.cpu_spp or (192 if w["width"] * w["height"] < 10 ** 6 else 8)
+    cw, ch = w["width"], w["height"]
     t0 = time.time()
-    o = O.OracleScene(os.path.join(ROOT, w["xml"]), w["width"], w["height"], spp)
+    o = O.OracleScene(os.path.join(ROOT, w["xml"]), cw, ch, spp)
     load_s = time.time() - t0                                   # OBJ parse + SAH BVH build (one thread, the reference's order)
     sec, st = o.render(0, spp, mode=0, threads=threads)
-    n = w["width"] * w["height"] * spp
+    n = cw * ch * spp
     spp1 = max(1, spp // 16)
     sec1, _ = o.render(0, spp1, mode=0, threads=1)
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
     return {"value": round(n / sec / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": "%dx%d, %d spp of the same scene (%.1f s), reference block-stream mode; the unmodified reference measured 1.62 Msamples/s on 8 threads in the survey container" % (
-                w["width"], w["height"], spp, sec),
+                cw, ch, spp, sec),
             "mrays_per_s": round((st["closest"] + st["shadow"]) / sec / 1e6, 3),
-            "single_thread": {"value": round(w["width"] * w["height"] * spp1 / sec1 / 1e6, 4), "sample": "%d spp (%.1f s)" % (spp1, sec1)},
-            "cpu_model": model, "host_cpus": os.cpu_count(), "scene_load_and_bvh_build_s": round(load_s, 3)}
+            "single_thread": {"value": round(cw * ch * spp1 / sec1 / 1e6, 4), "sample": "%d spp (%.1f s)" % (spp1, sec1)},
+            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "scene_load_and_bvh_build_s": round(load_s, 3)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="table", choices=list(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--cpu-spp", type=int, default=192)
+    ap.add_argument("--workload", default="c4", choices=list(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the workload's)")
+    ap.add_argument("--bvh", default="", choices=["", "host", "device"], help="default: device for c4, host (the reference's tree and order) otherwise")
+    ap.add_argument("--cpu-spp", type=int, default=0)
+    ap.add_argument("--cpu-c4-side", type=int, default=707)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--c4-side", type=int, default=0)
     ap.add_argument("--partition", default="spp", choices=["spp", "tiles"],
@@ -144,6 +143,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     import torch
     import nori_hip as NH
+    from nori_hip import synthetic
     from nori_hip.partition import spp_slice, tile_bands, allreduce_film
     dist = None
     if world > 1:
@@ -155,9 +155,11 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.spp:
         w["spp"] = args.spp
+    bvh = args.bvh or os.environ.get("NORI_HIP_BVH") or ("device" if w["xml"] is None else "host")
+    os.environ["NORI_HIP_BVH"] = bvh
     t0 = time.time()
     if w["xml"] is None:
-        hs = make_c4(args.c4_side or w["n_side"], w["width"], w["height"], w["spp"])
+        hs = synthetic.make_c4(args.c4_side or w["n_side"], w["width"], w["height"], w["spp"])
     else:
         hs = NH.HostScene(os.path.join(ROOT, w["xml"]), w["width"], w["height"], w["spp"])
     load_s = time.time() - t0
@@ -169,18 +171,31 @@ def main():
     film = film_tensor(ctx, torch) if world > 1 else None
     spp = w["spp"]
     tiles = args.partition == "tiles"
+    do_filter = bool(w.get("filter"))
     samples_per_step = w["width"] * w["height"] * spp                 # per rank (spp slices) or per job (tiles)
+    phase = {"render": 0.0, "reduce": 0.0, "filter": 0.0}
 
-    def step(k):
+    def step(k, timed=False):
         ctx.clear_film()
+        t_a = time.perf_counter()
         if tiles:
-            for y0, y1 in tile_bands(rank, world, w["height"]):      # this rank's bands, all samples
-                ctx.render(0, spp, tile=(0, y0, w["width"], y1))
+            ctx.render_tiles(0, spp, [(0, y0, w["width"], y1) for y0, y1 in tile_bands(rank, world, w["height"])])   # this rank's bands, ONE call
         else:
             ctx.render(*spp_slice(rank, world, spp))      # this rank's spp slice
+        if film is not None or do_filter:
+            ctx.synchronize()                             # film complete before the collective / the filter reads it
+        t_b = time.perf_counter()
         if film is not None:
-            ctx.synchronize()                             # film complete before the collective reads it
             allreduce_film(film, dist)
+            torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        if do_filter and rank == 0:
+            # configs[4]: the filter pass runs once, on the reduced film, on rank 0 (11 ms at 4K against seconds of rendering;
+            # the other ranks wait at the next barrier) - cuda/filter.cc.cu:125-176 after src/block.cpp:131-140's merge
+            ctx.filter(**FILTER_PARAMS)
+        t_d = time.perf_counter()
+        if timed:
+            phase["render"] += t_b - t_a; phase["reduce"] += t_c - t_b; phase["filter"] += t_d - t_c
 
     def sync():
         ctx.synchronize()
@@ -193,16 +208,13 @@ def main():
         step(k)
     sync()
     ctx.reset_stats()
-    kernel_ms = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
-        if world == 1 and k == args.steps - 1:
-            pass
+        step(k, True)
     sync()
     dt = time.perf_counter() - t0
     st = ctx.stats()
-    # dominant kernel: the extend stage (k_trace_pool<closest>) of the wavefront pipeline, timed by the library with
+    # dominant kernel: the trace stage (k_trace_pool) of the wavefront pipeline, timed by the library with
     # HIP events around every one of its launches on the context's stream; with NORI_HIP_PIPELINE=mega the single
     # persistent kernel (k_render_w4), timed the same way around its last launch
     wavefront = st["extend_launches"] > 0
@@ -212,58 +224,66 @@ def main():
         k_rays, k_boxes, k_prims = st["extend_rays"] / launches, st["extend_boxes"] / launches, st["extend_prims"] / launches
     else:
         kernel_ms = st["render_ms"]
+    rays_rank = float(st["closest_rays"] + st["shadow_rays"])
     if dist is not None:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        rsum = torch.tensor([rays_rank], device="cuda", dtype=torch.float64)
+        dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+        rays_job = float(rsum.item())
+    else:
+        rays_job = rays_rank
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
     total_samples = samples_per_step * args.steps * (1 if tiles else world)
-    rays = (st["closest_rays"] + st["shadow_rays"]) / args.steps            # this rank, per step
-    # algorithmic bytes per step: 32 B per node box tested + 40 B per primitive tested
-    # + 44 B ray in + 16 B hit out per ray + 2 x 16 B film read-modify-write per camera sample
+    rays = rays_rank / args.steps                                              # this rank, per step
+    # algorithmic bytes: 32 B per box tested + 40 B per primitive record tested + 44 B ray in + 16 B hit out per ray
     if wavefront:
-        alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays              # per extend launch
-        kname = "k_trace_pool<TK_BOTH>" if os.environ.get("NORI_HIP_MERGE", "1") != "0" else "k_trace_pool<TK_EXTEND>"
+        alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays              # per trace launch
+        kname = ctx.trace_kernel_name()
     else:
         alg_bytes = (32.0 * st["boxes_tested"] + 40.0 * st["prims_tested"]) / args.steps + 60.0 * rays + 32.0 * samples_per_step
         kname = "k_render_ext" if info_ext else "k_render_w%s" % os.environ.get("NORI_HIP_MEGA_WAVES", "4")
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, scratch/pmc.sh), which
-    # cannot run inside this process: the committed measurement of this workload and pipeline, if there is one
+    # HBM bytes per launch of the same kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, scratch/pmc.sh; the doubling
+    # holds for scattered reads too: scratch/fetchprobe.hip, profiles/r02_fetchprobe.txt), which cannot run inside this
+    # process: the committed measurement of this workload, tree and kernel, if there is one
     traffic, issue = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.workload)
-    if os.path.exists(tpath) and not args.spp:
+    tpath = os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % args.workload)
+    if os.path.exists(tpath) and not args.spp and not args.c4_side:
         tj = json.load(open(tpath))
-        if tj.get("kernel") == kname:
+        if tj.get("kernel") == kname and tj.get("bvh", bvh) == bvh:
             traffic = int(tj["traffic_bytes_per_launch"])
             issue = tj.get("valu_issue_busy")
     if traffic is not None and traffic < 0.5 * alg_bytes:
         roof_note = ("algorithmic bytes (SURVEY 8d) count every box and record test at full size; on this scene the nodes and records stay in L1/L2 "
-                     "(traffic = HBM bytes per launch from the committed PMC passes), so frac can pass 1: what bounds the kernel is vector-ALU issue "
+                     "(traffic = HBM bytes per launch from the committed PMC passes), so frac is not an HBM fraction here: what bounds the kernel is vector-ALU issue "
                      "under divergence (valu_issue_busy, same passes), see DESIGN.md 5")
     else:
-        roof_note = "algorithmic bytes per SURVEY 8d; traffic = HBM bytes per launch from the committed PMC passes (null: not measured for this workload and pipeline)"
+        roof_note = "algorithmic bytes per SURVEY 8d, counted by the kernel itself; traffic = HBM bytes per launch from the committed PMC passes (null: not measured for this workload, tree and kernel)"
     out = {
         "metric": "Msamples/s (path_mis, whole node)", "value": round(total_samples / dt / 1e6, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if w["xml"] is None else "reference scene files (scenes/)",
         "config": {"workload": w["name"], "width": w["width"], "height": w["height"], "spp_per_gpu": spp, "triangles": info["prims"],
-                   "bvh_nodes_64B": info["wide_nodes"], "partition": ("interleaved 32-row bands" if tiles else "spp slices") + ", RCCL all-reduce of the fp32 film" if world > 1 else "single GPU",
+                   "partition": (("interleaved 32-row bands, one render call per rank" if tiles else "spp slices") + ", RCCL all-reduce of the fp32 film") if world > 1 else "single GPU",
                    "scene_load_s": round(load_s, 2), "bvh_build_s": round(hs.bvh_build_seconds(), 3),
-                   "bvh": ("device LBVH, %.1f ms, %d of %d nodes used, depth %d" % (bi["build_ms"], bi["n_used"], bi["n_nodes"], bi["depth"])) if bi["n_nodes"] or bi["build_ms"] else "host SAH (reference order)"},
-        "mrays_per_s": round(rays * world * args.steps / dt / 1e6, 2),
-        "rays_per_sample": round(rays / samples_per_step, 3),
+                   "bvh": ("device-built, %.1f ms, %d nodes, depth %d" % (bi["build_ms"], bi["n_used"], bi["depth"])) if bvh == "device" else "host SAH (reference order), %d 64-byte nodes" % info["wide_nodes"]},
+        "mrays_per_s": round(rays_job / dt / 1e6, 2),
+        "rays_per_sample": round(rays / (samples_per_step if not tiles else max(1, samples_per_step // world)), 3),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "valu_issue_busy": issue,
                      "note": roof_note,
                      "kernel_ms": round(kernel_ms, 4), "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "boxes_tested_per_ray": round(st["boxes_tested"] / args.steps / rays, 2), "prims_tested_per_ray": round(st["prims_tested"] / args.steps / rays, 2)},
+                     "boxes_tested_per_ray": round(st["boxes_tested"] / max(1.0, rays_rank), 2), "prims_tested_per_ray": round(st["prims_tested"] / max(1.0, rays_rank), 2)},
     }
+    if do_filter or world > 1:
+        out["phases_ms_per_step"] = {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()}
     if not args.no_cpu and world == 1:
         cb = cpu_baseline(w, args)
         if cb:

@@ -112,23 +112,35 @@ __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const
 
 // ---------------------------------------------------------------------------------------------------------
 struct RenderJob {
-    int x0, y0, tw, th;               // tile origin and size
+    int x0, y0, tw, th;               // the tile (n_tiles == 1)
     int spp_begin, nspp;
-    unsigned long long total;         // tw*th*nspp work items
+    unsigned long long total;         // camera samples of the call
+    unsigned long long padded_total;  // work items: 64 per 8x8 patch and sample, edge patches padded
+    int n_tiles;                      // > 1: the call renders a list of tiles (nori_hip_render_tiles)
+    const int4 *tiles;                // x0, y0, tw, th per tile (device memory)
+    const unsigned int *patch_first;  // n_tiles + 1: patches before each tile
 };
 
 // Work item w -> (8x8 pixel patch, sample, lane): the 64 items of a chunk are the 64 pixels of one patch for one
-// sample index, so the primary rays of a freshly started wave are coherent.
-__device__ __forceinline__ void work_to_sample(const RenderJob &job, unsigned long long w, int &px, int &py, int &s) {
+// sample index, so the primary rays of a freshly started wave are coherent.  Patches are numbered tile after tile.
+// false: padding of an edge patch (the pixel lies outside its tile).
+__device__ __forceinline__ bool work_to_sample(const RenderJob &job, unsigned long long w, int &px, int &py, int &s) {
     unsigned int lane = (unsigned int) (w & 63u);
     unsigned long long chunk = w >> 6;
-    int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
     unsigned long long patch = chunk / (unsigned long long) job.nspp;
     s = job.spp_begin + (int) (chunk % (unsigned long long) job.nspp);
+    int x0 = job.x0, y0 = job.y0, tw = job.tw, th = job.th;
+    if (job.n_tiles > 1) {
+        int lo = 0, hi = job.n_tiles - 1;                                  // last tile whose first patch is <= patch
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((unsigned long long) job.patch_first[mid] <= patch) lo = mid; else hi = mid - 1; }
+        const int4 t = job.tiles[lo];
+        x0 = t.x; y0 = t.y; tw = t.z; th = t.w; patch -= job.patch_first[lo];
+    }
+    const int ptx = (tw + 7) >> 3;
     int pyi = (int) (patch / (unsigned long long) ptx), pxi = (int) (patch % (unsigned long long) ptx);
-    (void) pty;
-    px = job.x0 + pxi * 8 + (int) (lane & 7u);
-    py = job.y0 + pyi * 8 + (int) (lane >> 3);
+    px = x0 + pxi * 8 + (int) (lane & 7u);
+    py = y0 + pyi * 8 + (int) (lane >> 3);
+    return px < x0 + tw && py < y0 + th;
 }
 
 // ImageBlock::put(sample) as written (src/block.cpp:93-111: single-pixel add, then return) in the coordinates of
@@ -165,6 +177,7 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
 // Work items are handed out ND_WORK_GRAB at a time per wave (one atomic by one lane) and dealt to the lanes whose
 // path has ended with a ballot + prefix count, so the global counter sees one atomic per ND_WORK_GRAB samples.
 #define ND_WORK_GRAB 256u
+#define ND_MAX_TILES 65536          /* tiles of one nori_hip_render_tiles call (a 4K image has 8 160 blocks of 32 x 32) */
 // Workgroups of 256 lanes; LDS holds the traversal stacks (MEGA_DEPTH entries per lane) and, in the rest of the
 // workgroup's share, the top `n_cached` nodes of the tree.  The kernel is latency-bound (a dependent node or record
 // fetch per trip), so it is built for several register budgets (waves per SIMD) and the host picks one.
@@ -184,8 +197,7 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
     PathState ps; Pcg32 rng; F2 pixel_sample = f2(0.f, 0.f); int px = 0, py = 0;
     bool alive = false;
     const unsigned int lane = threadIdx.x & 63u;
-    const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
-    const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
+    const unsigned long long padded_total = job.padded_total;
     unsigned long long cursor = 0, end = 0;                               // wave-uniform: work items [cursor, end) are ours
     bool exhausted = false;                                               // wave-uniform
     for (;;) {
@@ -201,8 +213,8 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
             if (cursor < end) {
                 const unsigned long long w = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) dead, 0u));
                 if (!alive && w < end) {
-                    int s; work_to_sample(job, w, px, py, s);
-                    if (px < job.x0 + job.tw && py < job.y0 + job.th) {                   // else: padding of an edge patch
+                    int s;
+                    if (work_to_sample(job, w, px, py, s)) {                              // else: padding of an edge patch
                         rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) s);
                         F2 j = rng.next2D();
                         pixel_sample = f2((float) px + j.x, (float) py + j.y);
@@ -345,8 +357,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     __shared__ unsigned int l_regen, l_keep;
     __shared__ unsigned long long b_work; __shared__ unsigned int b_live;
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const int ptx = (job.tw + 7) >> 3, pty = (job.th + 7) >> 3;
-    const unsigned long long padded_total = (unsigned long long) ptx * pty * job.nspp * 64ull;
+    const unsigned long long padded_total = job.padded_total;
     const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
     const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
     unsigned int n_invalid = 0, n_degenerate = 0;
@@ -435,8 +446,8 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
         const unsigned int e = run_list[r], slot = lo + (e & 0x7fffu);
         const unsigned long long w = base_w + r;
         if (w < padded_total) {
-            int px, py, sidx; work_to_sample(job, w, px, py, sidx);
-            if (px < job.x0 + job.tw && py < job.y0 + job.th) {
+            int px, py, sidx;
+            if (work_to_sample(job, w, px, py, sidx)) {
                 Pcg32 rng; rng.seed((uint64_t) py * (uint64_t) sc.cam.width + (uint64_t) px, (uint64_t) sidx);
                 F2 j = rng.next2D();
                 F2 pixel_sample = f2((float) px + j.x, (float) py + j.y);
@@ -942,6 +953,7 @@ struct NoriHipContext {
     float lbvh_big = 0.25f;           // records longer than this fraction of the scene get their own subtree (NORI_HIP_LBVH_BIG, 0 = off)
     float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
     unsigned long long *d_counter = nullptr; DevStats *d_stats = nullptr;
+    int *d_tiles = nullptr;           // nori_hip_render_tiles: ND_MAX_TILES x (x0, y0, w, h), then ND_MAX_TILES + 1 patch offsets
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     NoriHipStats stats;
     int n_cus = 256;
@@ -1025,6 +1037,7 @@ static int create_impl(NoriHipContext *c, int device) {
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipMalloc((void **) &c->d_counter, sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **) &c->d_stats, ND_STRIPES * sizeof(DevStats)));
+    HIPCHK(hipMalloc((void **) &c->d_tiles, (size_t) (5 * ND_MAX_TILES + 1) * sizeof(int)));
     HIPCHK(hipMemset(c->d_stats, 0, ND_STRIPES * sizeof(DevStats)));
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
@@ -1074,7 +1087,7 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
-    hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
+    hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_tiles); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
     hipFree(ctx->d_qlive); hipFree(ctx->d_filt);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
@@ -1317,14 +1330,46 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     return NORI_HIP_OK;
 }
 
+static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end);
+
 int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp_begin, int spp_end) {
+    const int t[4] = {x0, y0, x1, y1};
+    return render_impl(ctx, t, 1, spp_begin, spp_end);
+}
+int nori_hip_render_tiles(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end) {
+    return render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
+}
+
+static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end) {
     SCENECHK(ctx);
     const int W = ctx->sc.cam.width, H = ctx->sc.cam.height;
-    if (x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 >= x1 || y0 >= y1) return fail(NORI_HIP_EINVAL, "tile outside the image");
+    if (!tiles_xyxy || n_tiles < 1 || n_tiles > ND_MAX_TILES) return fail(NORI_HIP_EINVAL, "tile list is null, empty or longer than " + std::to_string(ND_MAX_TILES));
     if (spp_begin < 0 || spp_end <= spp_begin) return fail(NORI_HIP_EINVAL, "empty sample range");
     if (ctx->sc.n_emitters == 0 && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
-    RenderJob job; job.x0 = x0; job.y0 = y0; job.tw = x1 - x0; job.th = y1 - y0; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin;
-    job.total = (unsigned long long) job.tw * job.th * job.nspp;
+    RenderJob job; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin; job.total = 0; job.n_tiles = n_tiles;
+    job.tiles = nullptr; job.patch_first = nullptr;
+    std::vector<int> h_tiles((size_t) 4 * n_tiles); std::vector<unsigned int> h_first((size_t) n_tiles + 1, 0u);
+    unsigned long long patches = 0;
+    for (int k = 0; k < n_tiles; ++k) {
+        const int x0 = tiles_xyxy[4 * k], y0 = tiles_xyxy[4 * k + 1], x1 = tiles_xyxy[4 * k + 2], y1 = tiles_xyxy[4 * k + 3];
+        if (x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 >= x1 || y0 >= y1) return fail(NORI_HIP_EINVAL, "tile " + std::to_string(k) + " lies outside the image or is empty");
+        h_tiles[4 * k] = x0; h_tiles[4 * k + 1] = y0; h_tiles[4 * k + 2] = x1 - x0; h_tiles[4 * k + 3] = y1 - y0;
+        h_first[k] = (unsigned int) patches;
+        patches += (unsigned long long) ((x1 - x0 + 7) >> 3) * (unsigned long long) ((y1 - y0 + 7) >> 3);
+        job.total += (unsigned long long) (x1 - x0) * (y1 - y0) * job.nspp;
+    }
+    if (patches > 0xffffffffull) return fail(NORI_HIP_EINVAL, "tile list covers too many pixels");
+    h_first[n_tiles] = (unsigned int) patches;
+    job.x0 = h_tiles[0]; job.y0 = h_tiles[1]; job.tw = h_tiles[2]; job.th = h_tiles[3];
+    job.padded_total = patches * (unsigned long long) job.nspp * 64ull;
+    if (n_tiles > 1) {
+        // (tiles must not overlap if every sample is to be rendered once; the library does not check that)
+        HIPCHK(hipStreamSynchronize(ctx->stream));                            // the previous call may still read the table
+        HIPCHK(hipMemcpyAsync(ctx->d_tiles, h_tiles.data(), h_tiles.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_tiles + 4 * ND_MAX_TILES, h_first.data(), h_first.size() * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));                            // h_tiles / h_first are locals
+        job.tiles = reinterpret_cast<const int4 *>(ctx->d_tiles); job.patch_first = reinterpret_cast<const unsigned int *>(ctx->d_tiles + 4 * ND_MAX_TILES);
+    }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
     const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS, direct = ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS;
     if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced) || mats || direct) {

@@ -83,6 +83,7 @@ def hip_lib():
         L.nori_hip_camera_rays.argtypes = [vp, vp, sz, vp]
         L.nori_hip_li_samples.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
         L.nori_hip_render.argtypes = [vp, i32, i32, i32, i32, i32, i32]
+        L.nori_hip_render_tiles.argtypes = [vp, vp, i32, i32, i32]
         L.nori_hip_clear_film.argtypes = [vp]
         L.nori_hip_film_dims.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.nori_hip_read_film.argtypes = [vp, vp]
@@ -217,6 +218,17 @@ class Context:
             rows, cols, b = self.film_dims()
             tile = (0, 0, cols - 2 * b, rows - 2 * b)
         _hchk(self.L.nori_hip_render(self.h, tile[0], tile[1], tile[2], tile[3], spp_begin, spp_end))
+
+    def render_tiles(self, spp_begin, spp_end, tiles):
+        """tiles: [(x0, y0, x1, y1), ...] rendered in one pass (nori_hip_render_tiles)"""
+        t = np.ascontiguousarray(tiles, np.int32).reshape(-1, 4)
+        if len(t) == 0:
+            return                                     # a rank without tiles has nothing to render
+        _hchk(self.L.nori_hip_render_tiles(self.h, _vp(t), len(t), spp_begin, spp_end))
+
+    def trace_kernel_name(self):
+        """the kernel bench.py's roofline is quoted on (the trace stage of the wavefront pipeline)"""
+        return "k_trace_pool<TK_BOTH>" if os.environ.get("NORI_HIP_MERGE", "1") != "0" else "k_trace_pool<TK_EXTEND>"
 
     def clear_film(self):
         _hchk(self.L.nori_hip_clear_film(self.h))

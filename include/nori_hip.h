@@ -229,6 +229,12 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
  * (src/render.cpp:151-190, src/block.cpp:93-111). */
 int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp_begin, int spp_end);
 
+/* The same for a list of n_tiles tiles (x0, y0, x1, y1 each; at most 65536, not overlapping) in ONE pass: one pool fill, one
+ * tail, whatever the number of tiles.  This is what a rank of a tile-partitioned job calls with its share of the image blocks.
+ * Replaces the reference's loop over the blocks a worker thread is handed by the BlockGenerator
+ * (src/render.cpp:157-183, src/block.cpp:163-195). */
+int nori_hip_render_tiles(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end);
+
 int nori_hip_clear_film(NoriHipContext *ctx);
 /* film = (height + 2*border) x (width + 2*border) float4 (r, g, b, weight) sums, row-major: ImageBlock's own
  * layout (include/nori/block.h:48).  nori_hip_film_dims reports rows, cols, border. */

@@ -1,0 +1,146 @@
+"""GPU: the synthetic 10M-triangle workload of BASELINE config 4 (nori_hip/synthetic.py) and the deep-tree machinery.
+
+Reduced size (n_side 300: 180 018 triangles), written as the reference's own files (XML + OBJ) and loaded by the host
+library and by the oracle: hits and Li against the oracle with the reference-order host tree, and the device-built tree
+against it.  Full size (n_side 2236: 10.0 M triangles, device-built tree): size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+import nori_hip as NH
+import oracle_lib as O
+from nori_hip import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def hits_as_u32(h):
+    return np.frombuffer(h.tobytes(), np.uint32).reshape(-1, 4)
+
+
+@pytest.fixture(scope="module")
+def c4_small(tmp_path_factory):
+    d = tmp_path_factory.mktemp("c4")
+    xml = synthetic.write_c4(str(d), 300, 96, 96, 4)
+    return xml
+
+
+def camera_and_bounce_rays(ctx, W, H, n, seed):
+    rng = np.random.default_rng(seed)
+    ps = (rng.random((n, 2)) * [W, H]).astype(np.float32)
+    rays = ctx.camera_rays(ps)
+    hits, full = ctx.trace(rays, full=True)
+    ok = hits["prim"] != NH.MISS
+    # bounce rays: from the hit point into a random direction of the upper hemisphere of the shading normal
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    nrm = full[:, 5:8]
+    flip = (d * nrm).sum(1) < 0
+    d[flip] = -d[flip]
+    b = np.zeros((n, 8), np.float32)
+    b[:, 0:3] = full[:, 0:3]; b[:, 3] = 1e-3; b[:, 4:7] = d; b[:, 7] = np.inf
+    return rays, b[ok]
+
+
+def test_c4_reduced_hits_and_li_against_oracle_with_the_reference_order_tree(c4_small):
+    W = H = 96
+    hs = NH.HostScene(c4_small, W, H, 4)
+    ctx = hs.preprocess()
+    o = O.OracleScene(c4_small, W, H, 4)
+    assert hs.info()["prims"] == 180018 == o.info()["prims"]
+    rays, bounce = camera_and_bounce_rays(ctx, W, H, 20000, 3)
+    assert np.array_equal(hits_as_u32(ctx.trace(rays)), o.trace(rays))                 # prim id, t, u, v bit-exact
+    assert np.array_equal(hits_as_u32(ctx.trace(bounce)), o.trace(bounce))
+    sh = bounce.copy(); sh[:, 7] = 0.7
+    assert np.array_equal(ctx.trace(sh, any_hit=True)["prim"], o.trace(sh, any_hit=True)[:, 0])
+    n = 4096
+    st = np.arange(n, dtype=np.uint64)
+    li = ctx.li_samples(st, np.zeros(n, np.uint64), rays=rays[:n])
+    oli = o.li_rays(rays[:n], st, np.zeros(n, np.uint64))
+    err = np.abs(li - oli).max(1) / np.maximum(np.abs(oli).max(1), 1e-3)
+    assert (err < 1e-3).mean() > 0.97, (err < 1e-3).mean()
+    bad = err >= 1e-3
+    # the samples that branch differently (device libm ulps at a comparison) are bounded in what they contribute to the mean
+    assert np.abs((li[bad] - oli[bad]).sum(0)).max() / n < 5e-3 * max(oli.mean(), 1e-6)
+    # image at matched streams
+    ctx.clear_film(); ctx.reset_stats(); ctx.render(0, 4)
+    img, film = ctx.read_bitmap(), ctx.read_film()
+    _, ost = o.render(0, 4, mode=1, threads=8)
+    assert np.array_equal(film[:, :, 3], o.film()[:, :, 3])
+    rel = np.abs(img.mean((0, 1)) - o.bitmap().mean((0, 1))) / o.bitmap().mean((0, 1))
+    assert rel.max() < 2e-3, rel
+    s = ctx.stats()
+    assert abs(s["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"] and abs(s["shadow_rays"] - ost["shadow"]) < 0.01 * ost["shadow"]
+    hs.close()
+
+
+def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small):
+    W = H = 96
+    hs = NH.HostScene(c4_small, W, H, 4)
+    ctx = hs.preprocess()
+    os.environ["NORI_HIP_BVH"] = "device"
+    try:
+        hd = NH.HostScene(c4_small, W, H, 4)
+        cd = hd.preprocess()
+    finally:
+        del os.environ["NORI_HIP_BVH"]
+    bi = cd.build_info()
+    assert bi["n_used"] > 0 and 0 < bi["depth"] <= 62
+    rays, bounce = camera_and_bounce_rays(ctx, W, H, 20000, 4)
+    for r in (rays, bounce):
+        a, b = ctx.trace(r), cd.trace(r)
+        same = a["prim"] == b["prim"]
+        # another primitive only where two tie in t (shared edges of the height field), never another distance
+        assert same.mean() > 0.995, same.mean()
+        assert np.array_equal(a["t"][same], b["t"][same])
+        assert np.allclose(a["t"][~same], b["t"][~same], rtol=1e-5)
+    sh = bounce.copy(); sh[:, 7] = 0.7
+    assert np.array_equal(ctx.trace(sh, any_hit=True)["prim"], cd.trace(sh, any_hit=True)["prim"])
+    # the two trees render the same image up to the ties
+    ctx.clear_film(); ctx.render(0, 4); cd.clear_film(); cd.render(0, 4)
+    fa, fb = ctx.read_film(), cd.read_film()
+    assert np.array_equal(fa[:, :, 3], fb[:, :, 3])
+    assert abs(fa[:, :, :3].sum() - fb[:, :, :3].sum()) < 2e-3 * fa[:, :, :3].sum()
+    hs.close(); hd.close()
+
+
+def test_c4_full_size_properties_on_the_device_built_tree():
+    """10.0 M triangles: tree depth within the traversal stack, every camera ray hits (closed box), hit distances consistent
+    with the hit points, linearity in spp of the film, ray counts proportional to samples."""
+    W = H = 256
+    os.environ["NORI_HIP_BVH"] = "device"
+    try:
+        hs = synthetic.make_c4(2236, W, H, 2)
+        ctx = hs.preprocess()
+    finally:
+        del os.environ["NORI_HIP_BVH"]
+    assert hs.info()["prims"] == 2 * 2236 * 2236 + 18
+    bi = ctx.build_info()
+    assert 0 < bi["depth"] <= 62 and bi["n_used"] > 10 ** 6, bi
+    rng = np.random.default_rng(11)
+    ps = (rng.random((100000, 2)) * [W, H]).astype(np.float32)
+    rays = ctx.camera_rays(ps)
+    hits, full = ctx.trace(rays, full=True)
+    assert (hits["prim"] != NH.MISS).all()                                     # closed scene
+    p = rays[:, 0:3] + hits["t"][:, None] * rays[:, 4:7]
+    assert np.abs(p - full[:, 0:3]).max() < 2e-3                               # barycentric hit point == o + t d (grazing hits on mm-sized triangles: t carries the error)
+    assert (np.abs(full[:, [0, 2]]) <= 1.0 + 1e-5).all() and (full[:, 1] >= -1e-5).all() and (full[:, 1] <= 2.0 + 1e-5).all()
+    # any-hit consistent with closest-hit: a ray cut short of its hit is unoccluded, one that passes it is occluded
+    sh = rays.copy(); sh[:, 7] = hits["t"] * 0.999; sh[:, 3] = 1e-3
+    assert (ctx.trace(sh, any_hit=True)["prim"] == NH.MISS).all()
+    sh[:, 7] = hits["t"] * 1.001
+    assert (ctx.trace(sh, any_hit=True)["prim"] == 1).all()
+    ctx.clear_film(); ctx.reset_stats(); ctx.render(0, 2)
+    f2, s2 = ctx.read_film(), ctx.stats()
+    ctx.render(2, 4)
+    f4, s4 = ctx.read_film(), ctx.stats()
+    assert f2[..., 3].sum() == W * H * 2 and f4[..., 3].sum() == W * H * 4 and s4["camera_samples"] == W * H * 4
+    assert s4["invalid_samples"] == 0
+    assert abs(f4[..., :3].sum() / f2[..., :3].sum() - 2.0) < 0.05
+    assert abs(s4["closest_rays"] / s2["closest_rays"] - 2.0) < 0.02
+    # tile list in one pass == whole image
+    ctx.clear_film(); ctx.render_tiles(0, 2, [(0, y, W, min(y + 32, H)) for y in range(0, H, 32)])
+    ft = ctx.read_film()
+    assert np.array_equal(ft[..., 3], f2[..., 3]) and np.allclose(ft, f2, rtol=1e-4, atol=1e-5)
+    hs.close()

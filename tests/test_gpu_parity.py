@@ -153,6 +153,16 @@ def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
             ctx.render(0, 8, tile=(0, y0, W, y1))
     bands = ctx.read_film()
     assert np.array_equal(bands[:, :, 3], whole[:, :, 3]) and np.allclose(bands, whole, rtol=1e-4, atol=1e-5)
+    # the same partition through nori_hip_render_tiles: each rank's bands in ONE call (ragged tiles included)
+    ctx.clear_film()
+    for r in range(3):
+        ctx.render_tiles(0, 8, [(0, y0, W, y1) for y0, y1 in tile_bands(r, 3, H, 32)])
+    assert np.array_equal(ctx.read_film()[:, :, 3], whole[:, :, 3]) and np.allclose(ctx.read_film(), whole, rtol=1e-4, atol=1e-5)
+    ctx.clear_film()
+    ctx.render_tiles(0, 8, [(0, 0, 13, 9), (13, 0, W, 9), (0, 9, 50, H), (50, 9, W, 41), (50, 41, W, H)])
+    assert np.array_equal(ctx.read_film()[:, :, 3], whole[:, :, 3]) and np.allclose(ctx.read_film(), whole, rtol=1e-4, atol=1e-5)
+    with pytest.raises(NH.NoriHipError):
+        ctx.render_tiles(0, 8, [(0, 0, W + 1, 9)])
     # checkpoint / resume: the film is sums + weights, so a saved film plus the remaining sample indices is the same render
     ctx.clear_film(); ctx.render(0, 5)
     saved = ctx.read_film()
