@@ -950,6 +950,7 @@ struct NoriHipContext {
     int integrator = NORI_HIP_INTEGRATOR_PATH_MIS;   // nori_hip_set_integrator
     lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
     uint32_t lbvh_leaf = 3;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF; measured: 2-3 best on every workload)
+    bool lbvh_plain = false;          // NORI_HIP_LBVH_MORTON=plain: x, y, z interleaved bit by bit instead of the planned bit order
     float lbvh_big = 0.25f;           // records longer than this fraction of the scene get their own subtree (NORI_HIP_LBVH_BIG, 0 = off)
     float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
     unsigned long long *d_counter = nullptr; DevStats *d_stats = nullptr;
@@ -1042,6 +1043,7 @@ static int create_impl(NoriHipContext *c, int device) {
     std::memset(&c->stats, 0, sizeof(c->stats));
     if (const char *e = getenv("NORI_HIP_PIPELINE")) { c->pipeline = (std::string(e) == "mega") ? 0 : 1; c->pipeline_forced = true; }
     if (const char *e = getenv("NORI_HIP_LBVH_BIG")) { float v = (float) atof(e); if (v >= 0.f) c->lbvh_big = v; }
+    if (const char *e = getenv("NORI_HIP_LBVH_MORTON")) c->lbvh_plain = std::string(e) == "plain";
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
@@ -1169,7 +1171,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         hipError_t e3_ = hipMalloc((void **) &ctx->d_nodes, (size_t) std::max<uint32_t>(d->n_prims - 1, 1u) * sizeof(NoriHipNode));
         std::string lerr;
         rc = (e1_ != hipSuccess || e2_ != hipSuccess || e3_ != hipSuccess) ? NORI_HIP_EDEVICE
-             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf, ctx->lbvh_big, ND_STACK - 2, ctx->lbvh, lerr);
+             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf, ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->lbvh, lerr);
         hipFree(tmp_prims); hipFree(tmp_shade);
         if (rc) { ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
         root = ctx->lbvh.root;

@@ -21,8 +21,10 @@ struct Result {
 // prims_in / shade_in: n records in any order (bit 31 of shape_flags ignored).  prims_out / shade_out: n records in
 // leaf order; nodes_out: max(n - 1, 1) nodes.  All device pointers.  Leaves hold at most `leaf_max` records; records
 // longer than `big` times the scene on some axis go into a subtree of their own under the root (0: off).
+// plain_morton: keys interleave x, y, z bit by bit; otherwise the bits are ordered by the size of the cell they halve and
+// bits finer than the typical record on their axis come last (see plan_bits in nori_lbvh.hip).
 // Returns 0 or a negative NORI_HIP_E* code with `err` set.
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
-          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, Result &res, std::string &err);
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, Result &res, std::string &err);
 
 } // namespace lbvh

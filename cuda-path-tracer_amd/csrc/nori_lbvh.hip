@@ -17,6 +17,7 @@
 #include <hipcub/hipcub.hpp>
 #include <vector>
 #include <algorithm>
+#include <cmath>
 
 namespace lbvh {
 namespace {
@@ -41,46 +42,52 @@ __device__ __forceinline__ void record_box(const NoriHipPrim &p, const NoriHipSh
     }
 }
 
-__global__ __launch_bounds__(256) void k_boxes(uint32_t n, const NoriHipPrim *prims, const NoriHipShadePrim *shade, float4 *pmin, float4 *pmax, uint32_t *cbounds) {
-    __shared__ uint32_t red[6];
-    if (threadIdx.x < 3) red[threadIdx.x] = 0xffffffffu; else if (threadIdx.x < 6) red[threadIdx.x] = 0u;
+// log2 of a box extent in 1/256ths, clamped to [2^-40, 2^40]: summed in integers, so the sum (and with it the bit plan of the
+// keys) does not depend on the order of the atomics
+__device__ __forceinline__ long long log2_fix(float e) { return (long long) (log2f(fminf(fmaxf(e, 9.0949470e-13f), 1.0995116e12f)) * 256.0f); }
+
+__global__ __launch_bounds__(256) void k_boxes(uint32_t n, const NoriHipPrim *prims, const NoriHipShadePrim *shade, float4 *pmin, float4 *pmax, uint32_t *cbounds,
+                                               long long *log_extent /* 3: sum over the records of log2(extent) per axis, 1/256ths */) {
+    __shared__ uint32_t red[6]; __shared__ long long lsum[3];
+    if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; lsum[threadIdx.x] = 0; } else if (threadIdx.x < 6) red[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    long long le[3] = {0, 0, 0};
     if (i < n) {
         float mn[3], mx[3]; record_box(prims[i], shade[i], mn, mx);
         pmin[i] = make_float4(mn[0], mn[1], mn[2], 0.f); pmax[i] = make_float4(mx[0], mx[1], mx[2], 0.f);
-        for (int a = 0; a < 3; ++a) { float c = 0.5f * (mn[a] + mx[a]); atomicMin(&red[a], f2o(c)); atomicMax(&red[3 + a], f2o(c)); }
+        for (int a = 0; a < 3; ++a) { float c = 0.5f * (mn[a] + mx[a]); atomicMin(&red[a], f2o(c)); atomicMax(&red[3 + a], f2o(c)); le[a] = log2_fix(mx[a] - mn[a]); }
+    }
+    for (int a = 0; a < 3; ++a) {
+        long long v = le[a];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd((unsigned long long *) &lsum[a], (unsigned long long) v);
     }
     __syncthreads();
-    if (threadIdx.x < 3) atomicMin(&cbounds[threadIdx.x], red[threadIdx.x]); else if (threadIdx.x < 6) atomicMax(&cbounds[threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x < 3) { atomicMin(&cbounds[threadIdx.x], red[threadIdx.x]); atomicAdd((unsigned long long *) &log_extent[threadIdx.x], (unsigned long long) lsum[threadIdx.x]); }
+    else if (threadIdx.x < 6) atomicMax(&cbounds[threadIdx.x], red[threadIdx.x]);
 }
 
-__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {         // bit k -> bit 3k
-    x &= 0x1fffffull;
-    x = (x | x << 32) & 0x1f00000000ffffull;
-    x = (x | x << 16) & 0x1f0000ff0000ffull;
-    x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
-}
+// Which bit of which axis' 21-bit cell coordinate goes where in the 63-bit key, most significant first (see plan_bits).
+struct BitPlan { unsigned char axis[63], bit[63]; };
 
 // Records whose box is longer than `big` times the extent of the centre bounds on some axis get the top key bit: they
 // sort behind all others and the hierarchy splits them off at the root, into a subtree of their own.  (A room-sized
 // wall triangle that shares a Morton cell with millimetre-sized ones would otherwise inflate every box above it.)
-__global__ __launch_bounds__(256) void k_morton(uint32_t n, const float4 *pmin, const float4 *pmax, const uint32_t *cbounds, float big, unsigned long long *keys, uint32_t *vals) {
+__global__ __launch_bounds__(256) void k_morton(uint32_t n, const float4 *pmin, const float4 *pmax, const uint32_t *cbounds, float big, BitPlan plan, unsigned long long *keys, uint32_t *vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 a = pmin[i], b = pmax[i];
     const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)}, e[3] = {b.x - a.x, b.y - a.y, b.z - a.z};
-    unsigned long long code = 0; bool large = false;
+    uint32_t q[3]; bool large = false;
     for (int k = 0; k < 3; ++k) {
         const float lo = o2f(cbounds[k]), hi = o2f(cbounds[3 + k]);
         float t = (hi > lo) ? (c[k] - lo) / (hi - lo) : 0.f;
-        t = fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
-        code |= spread21((unsigned long long) t) << (2 - k);
+        q[k] = (uint32_t) fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
         large = large || (big > 0.f && e[k] > big * (hi - lo));
     }
+    unsigned long long code = 0;
+    for (int p = 0; p < 63; ++p) code = (code << 1) | (unsigned long long) ((q[plan.axis[p]] >> plan.bit[p]) & 1u);
     keys[i] = code | (large ? 0x8000000000000000ull : 0ull); vals[i] = i;
 }
 
@@ -214,8 +221,32 @@ __global__ void k_mark_last(NoriHipPrim *pout, uint32_t pos) { pout[pos].shape_f
 
 } // namespace
 
+// The order of the key bits decides which axis the radix tree splits at each level.  A plain Morton code alternates x, y, z
+// whatever the geometry; on a scene whose primitives are long on one axis (a height field of needles: millimetres wide, a
+// tenth of the scene high) a third of the splits then cut along the axis on which every primitive overlaps its neighbours,
+// both children keep the parent's extent on the other two axes, and a ray that enters one enters both.  Here the bits are laid
+// out by the physical size of the cell they halve, largest first (so axes are split in proportion to the scene's shape), and
+// the bits of an axis that cut finer than the typical primitive's extent on that axis (geometric mean over the records) are
+// moved behind all the useful ones: they still order the records inside the finest useful cell, but split nothing before that.
+static BitPlan plan_bits(const float lo[3], const float hi[3], const long long log_extent[3], uint32_t n) {
+    struct Cand { double size; int axis, bit; bool useful; };
+    std::vector<Cand> c;
+    for (int a = 0; a < 3; ++a) {
+        const double ext = (double) hi[a] - (double) lo[a];
+        const double typical = std::exp2((double) log_extent[a] / 256.0 / (double) n);      // geometric mean of the records' extents
+        for (int k = 0; k < 21; ++k) {
+            const double cell = ext > 0 ? ext / std::exp2((double) (k + 1)) : 0.0;         // size of the halves this bit tells apart
+            c.push_back({cell, a, 20 - k, cell >= 0.75 * typical && cell > 0});
+        }
+    }
+    std::stable_sort(c.begin(), c.end(), [](const Cand &x, const Cand &y) { if (x.useful != y.useful) return x.useful; return x.size > y.size; });
+    BitPlan p;
+    for (int i = 0; i < 63; ++i) { p.axis[i] = (unsigned char) c[i].axis; p.bit[i] = (unsigned char) c[i].bit; }
+    return p;
+}
+
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
-          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, Result &res, std::string &err) {
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, Result &res, std::string &err) {
     std::vector<void *> owned; hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() { for (void *p : owned) (void) hipFree(p); owned.clear(); if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); e0 = e1 = nullptr; };
 #define LCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); cleanup(); return NORI_HIP_EDEVICE; } } while (0)
@@ -224,12 +255,13 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
     if (n >= 0x7fffffffu) { err = "lbvh: too many records"; return NORI_HIP_EINVAL; }
     const unsigned blocks = (n + 255u) / 256u;
     LCHK(hipEventCreate(&e0)); LCHK(hipEventCreate(&e1));
-    float4 *pmin, *pmax; uint32_t *cb;
-    LCHK(alloc((void **) &pmin, (size_t) n * 16)); LCHK(alloc((void **) &pmax, (size_t) n * 16)); LCHK(alloc((void **) &cb, 8 * 4));
+    float4 *pmin, *pmax; uint32_t *cb; long long *log_extent;
+    LCHK(alloc((void **) &pmin, (size_t) n * 16)); LCHK(alloc((void **) &pmax, (size_t) n * 16)); LCHK(alloc((void **) &cb, 8 * 4)); LCHK(alloc((void **) &log_extent, 3 * 8));
     const uint32_t cb_init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};     // [6] = tree depth, [7] = nodes in use
     LCHK(hipMemcpyAsync(cb, cb_init, sizeof(cb_init), hipMemcpyHostToDevice, stream));
+    LCHK(hipMemsetAsync(log_extent, 0, 3 * 8, stream));
     LCHK(hipEventRecord(e0, stream));
-    hipLaunchKernelGGL(k_boxes, dim3(blocks), dim3(256), 0, stream, n, prims_in, shade_in, pmin, pmax, cb);
+    hipLaunchKernelGGL(k_boxes, dim3(blocks), dim3(256), 0, stream, n, prims_in, shade_in, pmin, pmax, cb, log_extent);
     LCHK(hipGetLastError());
     res = Result();
     if (n <= leaf_max) {
@@ -258,7 +290,17 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
     unsigned long long *keys, *keys_s; uint32_t *vals, *vals_s;
     LCHK(alloc((void **) &keys, (size_t) n * 8)); LCHK(alloc((void **) &keys_s, (size_t) n * 8));
     LCHK(alloc((void **) &vals, (size_t) n * 4)); LCHK(alloc((void **) &vals_s, (size_t) n * 4));
-    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) cb, big, keys, vals);
+    BitPlan plan;
+    {
+        uint32_t h_b[8]; long long h_le[3];
+        LCHK(hipMemcpyAsync(h_b, cb, sizeof(h_b), hipMemcpyDeviceToHost, stream));
+        LCHK(hipMemcpyAsync(h_le, log_extent, sizeof(h_le), hipMemcpyDeviceToHost, stream));
+        LCHK(hipStreamSynchronize(stream));
+        float lo[3], hi[3]; for (int a = 0; a < 3; ++a) { lo[a] = o2f(h_b[a]); hi[a] = o2f(h_b[3 + a]); }
+        if (plain_morton) { for (int i = 0; i < 63; ++i) { plan.axis[i] = (unsigned char) (i % 3); plan.bit[i] = (unsigned char) (20 - i / 3); } }
+        else plan = plan_bits(lo, hi, h_le, n);
+    }
+    hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, stream, n, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) cb, big, plan, keys, vals);
     LCHK(hipGetLastError());
     size_t tmp_bytes = 0; void *tmp = nullptr;
     LCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, (int) n, 0, 64, stream));
