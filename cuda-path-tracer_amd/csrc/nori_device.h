@@ -92,9 +92,12 @@ struct DevScene {
     const NoriHipShadePrim *light_prims;
     const NoriHipTexture *textures;    // image tables (null when the scene has none)
     const uint8_t *tex_data;
+    const float4 *nodes4;              // the same tree as 128-byte four-box nodes (8 x float4 per node, see Trav::box_step4), or null
+    uint32_t root4;                    // child reference of the root in nodes4 numbering
     uint32_t root, n_emitters;
-    int ordered;                       // 0: the reference's child order (left first; decides ties, bit-exact hits).  1: nearer child first —
+    int ordered;                       // bit 0 clear: the reference's child order (left first; decides ties, bit-exact hits).  set: nearer child first —
                                        // fewer box tests, same hit except where two primitives tie within rounding (NORI_HIP_ORDER=near)
+                                       // bit 1 set (default): any-hit rays enter the nearer child first whatever bit 0 says (same answer for every order)
     int prim_lanes;                    // run-to-completion traversal: lanes that must wait at a leaf before a record step is issued
     uint32_t n_top;                    // nodes [0, n_top) are the top of the tree in breadth-first order (LDS cache candidates)
     float root_min[3], root_max[3];
@@ -264,6 +267,73 @@ template <bool ANY> struct Trav {
         if (hl & hr) stk.push(sp++, make_uint2(sw ? left : right, __float_as_uint(sw ? nl : nrr)));
         cur = hl ? (sw ? right : left) : (hr ? right : ND_POP); cur_near = (hl & !sw) ? nl : nrr;
     }
+    // ---- four-box nodes -------------------------------------------------------------------------------------------
+    // A 128-byte node holds the boxes and references of up to four children: an inner node of the binary tree with its
+    // inner children opened, i.e. its grandchildren in depth-first order (left-left, left-right, right-left, right-right;
+    // a child that is a leaf stays as it is), valid slots first.  Layout, 8 x float4:
+    //   0 min.x of the four children | 1 min.y | 2 min.z | 3 max.x | 4 max.y | 5 max.z | 6 child references | 7 unused
+    // One aligned 128-byte fetch - a whole HBM line, which a 64-byte node fetch moves as well (scratch/fetchprobe.hip) -
+    // decides four descents, and the chain of dependent fetches per ray is about half as long.
+    // Exactness: the boxes are bit-copies of the binary tree's.  A child's box lies inside its parent's and the slab test is
+    // monotone in the box (subtraction, multiplication by the reciprocal, min and max all are), so a box that passes implies
+    // that every box above it passes with the larger maxt it would have been tested with: skipping the opened node's own test
+    // changes no decision below it.  Visiting order: `ordered` = by entry distance (any-hit rays, device-built trees); otherwise
+    // slot order, which is the binary tree's depth-first order (left first, src/bvh.cpp:425-431), so ties in t fall as before.
+    // The children that pass are pushed far to near (or last to first), the first one becomes `cur`.
+#define ND_CE4(A, B) { const bool sw_ = key[B] < key[A]; const float tk_ = sw_ ? key[B] : key[A]; key[B] = sw_ ? key[A] : key[B]; key[A] = tk_; \
+                       const float tn_ = sw_ ? nr[B] : nr[A]; nr[B] = sw_ ? nr[A] : nr[B]; nr[A] = tn_; \
+                       const uint32_t tr_ = sw_ ? ref[B] : ref[A]; ref[B] = sw_ ? ref[A] : ref[B]; ref[A] = tr_; }
+    template <typename StackT> __device__ __forceinline__ void box4_finish(float nr[4], const bool hit[4], uint32_t ref[4], StackT &stk, const bool ordered) {
+        float key[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) key[k] = hit[k] ? (ordered ? nr[k] : (float) k) : ND_INF;
+        ND_CE4(0, 1) ND_CE4(2, 3) ND_CE4(0, 2) ND_CE4(1, 3) ND_CE4(1, 2)
+        const int n = (int) hit[0] + (int) hit[1] + (int) hit[2] + (int) hit[3];
+        if (n > 3) stk.push(sp++, make_uint2(ref[3], __float_as_uint(nr[3])));
+        if (n > 2) stk.push(sp++, make_uint2(ref[2], __float_as_uint(nr[2])));
+        if (n > 1) stk.push(sp++, make_uint2(ref[1], __float_as_uint(nr[1])));
+        cur = n ? ref[0] : ND_POP; cur_near = n ? nr[0] : cur_near;
+    }
+    // direction components all normal numbers: min/max form, as box_compute_fast
+    // (both forms return the number of boxes the node holds, for the statistics)
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step4_fast(const float4 *nodes4, StackT &stk, const bool ordered) {
+        const float4 *q = nodes4 + 8 * (size_t) cur;
+        const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5]; const float4 cr = q[6];
+        const float lx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ly[4] = {mny.x, mny.y, mny.z, mny.w}, lz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+        const float hx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, hy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, hz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+        uint32_t ref[4] = {__float_as_uint(cr.x), __float_as_uint(cr.y), __float_as_uint(cr.z), __float_as_uint(cr.w)};
+        float nr[4]; bool hit[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x1 = (lx[k] - o.x) * rcp.x, x2 = (hx[k] - o.x) * rcp.x;
+            const float y1 = (ly[k] - o.y) * rcp.y, y2 = (hy[k] - o.y) * rcp.y;
+            const float z1 = (lz[k] - o.z) * rcp.z, z2 = (hz[k] - o.z) * rcp.z;
+            const float nn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fminf(z1, z2));
+            const float ff = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2));
+            nr[k] = nn; hit[k] = (nn <= ff) & (mint <= ff) & (nn <= maxt) & (ref[k] != NORI_HIP_NO_CHILD);
+        }
+        const uint32_t n_valid = (uint32_t) (ref[0] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[1] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[2] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[3] != NORI_HIP_NO_CHILD);
+        box4_finish(nr, hit, ref, stk, ordered);
+        return n_valid;
+    }
+    // any ray: the reference's test as written (zero, denormal or NaN direction components)
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step4(const float4 *nodes4, StackT &stk, const bool ordered) {
+        const float4 *q = nodes4 + 8 * (size_t) cur;
+        const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5]; const float4 cr = q[6];
+        const float lx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ly[4] = {mny.x, mny.y, mny.z, mny.w}, lz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+        const float hx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, hy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, hz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+        uint32_t ref[4] = {__float_as_uint(cr.x), __float_as_uint(cr.y), __float_as_uint(cr.z), __float_as_uint(cr.w)};
+        float nr[4]; bool hit[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float bmin[3] = {lx[k], ly[k], lz[k]}, bmax[3] = {hx[k], hy[k], hz[k]};
+            float nn; const bool h = slab(bmin, bmax, o, d, rcp, mint, maxt, nn);
+            nr[k] = nn; hit[k] = h & (ref[k] != NORI_HIP_NO_CHILD);
+        }
+        const uint32_t n_valid = (uint32_t) (ref[0] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[1] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[2] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[3] != NORI_HIP_NO_CHILD);
+        box4_finish(nr, hit, ref, stk, ordered);
+        return n_valid;
+    }
     // one record of the current leaf; afterwards the lane is at the next record, in ND_POP (leaf finished) or done
     __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) { prim_step(sc, n_prims, ANY); }
     // `any`: stop at the first hit (a per-lane flag where one kernel traces shadow and extend rays together)
@@ -335,7 +405,7 @@ __device__ __forceinline__ bool trace(const DevScene &sc, const NodesT &nodes, c
     Trav<ANY> tv;
     // any-hit: maxt never shrinks, so the set of records reached and with it the answer is the same for every child
     // order; the nearer child first finds an occluder sooner.  closest-hit: the reference's order unless sc.ordered
-    const bool ordered = ANY || sc.ordered != 0;
+    const bool ordered = (ANY && (sc.ordered & 2)) || (sc.ordered & 1);
     tv.begin(sc, ray_in, n_nodes);
     for (;;) {
         const unsigned long long m_in = __ballot(tv.at_inner());
@@ -728,7 +798,7 @@ __device__ __forceinline__ bool trace_masked(const DevScene &sc, const Ray &ray,
     ScratchStack stk; GlobalNodes nodes; nodes.nodes = sc.nodes;
     Trav<false> tv; tv.begin(sc, ray, n_nodes);
     while (!tv.done()) {
-        if (tv.at_inner()) { if (tv.special) tv.box_step(nodes, stk, n_nodes, sc.ordered != 0); else tv.box_step_fast(nodes, stk, n_nodes, sc.ordered != 0); }
+        if (tv.at_inner()) { if (tv.special) tv.box_step(nodes, stk, n_nodes, (sc.ordered & 1) != 0); else tv.box_step_fast(nodes, stk, n_nodes, (sc.ordered & 1) != 0); }
         else if (tv.at_leaf()) {
             float4 A, B, C; tv.prim_fetch(sc, A, B, C);
             const uint32_t fl = __float_as_uint(C.z);

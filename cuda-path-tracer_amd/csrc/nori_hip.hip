@@ -524,12 +524,20 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // reference tests a leaf's box when it gets to it, after every earlier leaf (src/bvh.cpp:404-463): a lane parks its next
 // leaf only when the parked one is finished, and re-tests the entry distance against maxt at that moment - the same
 // test at the same point of the depth-first order, so the same records are tested with the same maxt, in the same order.
-template <int KIND, bool PROF, bool SPEC = false>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
+// WIDE: the tree is walked through its 128-byte four-box nodes (DevScene::nodes4, Trav::box_step4): every fetch uses a whole
+// HBM line and a ray's chain of dependent fetches is about half as long; up to three stack entries per visit, so the LDS part of
+// the stack is deeper (TRACE_DEPTH_W).
+#define TRACE_DEPTH_W 8
+#ifndef ND_WIDE_WAVES
+#define ND_WIDE_WAVES 5         /* waves per SIMD the four-box trace stage is built for */
+#endif
+template <int KIND, bool PROF, bool SPEC, bool WIDE>
+__device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
+    constexpr int DEPTH = WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
     extern __shared__ float4 dyn_lds[];
     const unsigned int nw = blockDim.x >> 6;
-    float4 *st_o_all = dyn_lds + nw * (TRACE_DEPTH * 64 * 8 / 16);
+    float4 *st_o_all = dyn_lds + nw * (DEPTH * 64 * 8 / 16);
     float4 *st_d_all = st_o_all + nw * 64, *st_r_all = st_d_all + nw * 64;
     unsigned int *st_slot_all = reinterpret_cast<unsigned int *>(st_r_all + nw * 64);
     float4 *const st_o = st_o_all + (threadIdx.x >> 6) * 64, *const st_d = st_d_all + (threadIdx.x >> 6) * 64, *const st_r = st_r_all + (threadIdx.x >> 6) * 64;
@@ -551,8 +559,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
-    uint2 stack_spill[ND_STACK - TRACE_DEPTH];
-    LdsStackT<TRACE_DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + wv * (TRACE_DEPTH * 64) + lane;
+    uint2 stack_spill[ND_STACK - DEPTH];
+    LdsStackT<DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + wv * (DEPTH * 64) + lane;
+    unsigned int n_boxes_lane = 0;                                       // WIDE: boxes of the nodes this lane visited
     // (an LDS copy of the top of the tree, CachedNodes, was measured here: no gain, and a branch per node visit)
     GlobalNodes nodes; nodes.nodes = sc.nodes;
     bool any = ANY;                                                      // this lane's ray is a shadow ray
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
                     if (KIND == TK_BOTH) any = (slot >> 31) != 0u;
                     tv.special = (slot & 0x40000000u) != 0u; slot &= 0x3fffffffu;
                     tv.o = f3(ro.x, ro.y, ro.z); tv.mint = ro.w; tv.d = f3(rd.x, rd.y, rd.z); tv.maxt = rd.w; tv.rcp = f3(rr.x, rr.y, rr.z);
-                    tv.sp = 0; tv.found = false; tv.cur = sc.root; tv.cur_near = -ND_INF;       // (the root box was tested at staging; the root may be a leaf)
+                    tv.sp = 0; tv.found = false; tv.cur = WIDE ? sc.root4 : sc.root; tv.cur_near = -ND_INF;       // (the root box was tested at staging; the root may be a leaf)
                     tv.hit.pos = 0xffffffffu; tv.hit.t = ND_INF; tv.hit.u = tv.hit.v = 0.f;
                     have = true;
                 }
@@ -646,12 +655,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         bool ran = false;
         if (m_in && (__popcll(m_in) >= thr.x || __ballot(tv.at_leaf()) == 0ull)) {
             if (PROF) { pf[1]++; pf[2] += __popcll(m_in); }
-            n_boxes += 2u * (unsigned int) __popcll(m_in);
             // shadow rays take the nearer child first (any child order gives the same any-hit answer), extend rays
             // the reference's order unless sc.ordered
-            const bool ord = ((KIND == TK_BOTH) ? any : ANY) || (sc.ordered != 0 && true);
-            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
-            else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
+            const bool ord = (((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 2)) || (sc.ordered & 1);
+            if (WIDE) {
+                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord); }
+                else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
+            } else {
+                n_boxes += 2u * (unsigned int) __popcll(m_in);
+                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
+                else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
+            }
             ran = true;
         }
         if (!SPEC) {
@@ -669,10 +683,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
             const unsigned long long m_in2 = __ballot(tv.at_inner());
             if ((unsigned int) __popcll(m_in2) >= (box2_lanes & 0xffu)) {
                 if (PROF) { pf[1]++; pf[2] += __popcll(m_in2); }
-                n_boxes += 2u * (unsigned int) __popcll(m_in2);
-                const bool ord = ((KIND == TK_BOTH) ? any : ANY) || sc.ordered != 0;
-                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
-                else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
+                const bool ord = (((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 2)) || (sc.ordered & 1);
+                if (WIDE) {
+                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord); }
+                    else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
+                } else {
+                    n_boxes += 2u * (unsigned int) __popcll(m_in2);
+                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
+                    else if (tv.at_inner()) tv.box_step(nodes, stk, dummy, ord);
+                }
             }
         }
         if (SPEC) {
@@ -693,6 +712,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
             }
         }
     }
+    if (WIDE) { unsigned int x = n_boxes_lane; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); n_boxes += __builtin_amdgcn_readfirstlane(x); }
     const unsigned long long v[4] = {n_rays, n_boxes, n_prims, n_rays_any};
     if (lane == 0 && (v[0] | v[1] | v[3])) {
         DevStats *st = my_stats(stats);
@@ -702,6 +722,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
         if (!ANY) { atomicAdd(&st->ext_rays, v[0] + v[3]); atomicAdd(&st->ext_nodes, v[1]); atomicAdd(&st->ext_prims, v[2]); }
         if (PROF) for (int k = 0; k < 10; ++k) atomicAdd(&st->prof[ANY ? 1 : 0][k], (unsigned long long) pf[k]);
     }
+}
+
+template <int KIND, bool PROF, bool SPEC = false>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
+    trace_pool_body<KIND, PROF, SPEC, false>(sc, pool, n_slots, stats, thr, box2_lanes, cnt);
+}
+// the merged trace stage over four-box nodes
+template <bool PROF, bool SPEC>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
+    trace_pool_body<TK_BOTH, PROF, SPEC, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt);
 }
 
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
@@ -942,6 +972,9 @@ struct NoriHipContext {
     hipStream_t stream = nullptr;
     bool have_scene = false;
     DevScene sc;
+    float4 *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;     // the tree as 128-byte four-box nodes (null: one-leaf tree, or too deep for the stack)
+    bool wide = true;                 // NORI_HIP_WIDE=0: the trace stage walks the 64-byte two-box nodes
+    size_t trace_lds_wide = 0;
     NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
     NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
@@ -975,6 +1008,8 @@ struct NoriHipContext {
     int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
+    bool any_near = true;             // NORI_HIP_ANYORDER=reference: any-hit rays walk the tree in the reference's order too (then every schedule and
+                                      // node width tests the same records; by default they enter the nearer child first, which finds occluders sooner)
     bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
     int prim_lanes = 1;               // see DevScene::prim_lanes (NORI_HIP_PRIM_LANES)
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
@@ -998,6 +1033,7 @@ struct NoriHipContext {
         return NORI_HIP_OK;
     }
     void free_scene() {
+        hipFree(d_nodes4); d_nodes4 = nullptr; n_nodes4 = 0;
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         hipFree(d_textures); hipFree(d_tex_data); d_textures = nullptr; d_tex_data = nullptr; ext = false;
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
@@ -1046,6 +1082,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_LBVH_MORTON")) c->lbvh_plain = std::string(e) == "plain";
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0;
+    if (const char *e = getenv("NORI_HIP_WIDE")) c->wide = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
     if (const char *e = getenv("NORI_HIP_DYN")) { int v = atoi(e); if (v >= 0 && v <= 90) c->dyn_pct = v; }
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
@@ -1056,6 +1093,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
     if (const char *e = getenv("NORI_HIP_ORDER")) c->ordered = std::string(e) == "near";
+    if (const char *e = getenv("NORI_HIP_ANYORDER")) c->any_near = std::string(e) != "reference";
     if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) c->trace_threads = v; }
     if (const char *e = getenv("NORI_HIP_MERGE")) c->merge_trace = atoi(e) != 0;
@@ -1081,6 +1119,11 @@ static int create_impl(NoriHipContext *c, int device) {
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_BOTH, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
+    c->trace_lds_wide = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH_W * 64 * 8 + 64 * 52);
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     return NORI_HIP_OK;
 }
 
@@ -1099,6 +1142,54 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     (void) hipGetLastError();
     delete ctx;
+    return NORI_HIP_OK;
+}
+
+// The uploaded binary tree as four-box nodes (Trav::box_step4): every inner node at an even depth with its inner children
+// opened, slots in the binary tree's depth-first order (left-left, left-right, right-left, right-right), valid slots first.
+// Also the check the kernels rely on: every node is reached once (no cycles, no shared subtrees) and the depth fits the stack.
+// out: 32 floats per node; depth: levels of inner nodes of the binary tree.
+static int collapse_host(const std::vector<NoriHipNode> &nodes, uint32_t root, std::vector<float> &out, uint32_t &root4, uint32_t &depth) {
+    out.clear(); depth = 0; root4 = root;
+    if (root & NORI_HIP_LEAF_BIT) return NORI_HIP_OK;
+    struct Item { uint32_t bin, level; };
+    std::vector<Item> queue; queue.push_back({root, 0});                     // binary nodes that become four-box nodes, in breadth-first order
+    std::vector<unsigned char> seen(nodes.size(), 0); seen[root] = 1;
+    const float inf = __builtin_huge_valf();
+    auto visit = [&](uint32_t r) { if (seen[r]) return false; seen[r] = 1; return true; };
+    for (size_t k = 0; k < queue.size(); ++k) {
+        const Item it = queue[k]; const NoriHipNode &w = nodes[it.bin];
+        float mn[4][3], mx[4][3]; uint32_t ref[4]; int m = 0;
+        for (int j = 0; j < 4; ++j) { ref[j] = NORI_HIP_NO_CHILD; for (int a = 0; a < 3; ++a) { mn[j][a] = inf; mx[j][a] = -inf; } }
+        depth = std::max(depth, it.level + 1);
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t r = side ? w.right : w.left;
+            if (r == NORI_HIP_NO_CHILD) continue;
+            if (r & NORI_HIP_LEAF_BIT) {
+                for (int a = 0; a < 3; ++a) { mn[m][a] = side ? w.rmin[a] : w.lmin[a]; mx[m][a] = side ? w.rmax[a] : w.lmax[a]; }
+                ref[m++] = r; continue;
+            }
+            if (!visit(r)) return fail(NORI_HIP_EINVAL, "node table is not a tree: node " + std::to_string(r) + " is reached twice");
+            const NoriHipNode &c = nodes[r];
+            depth = std::max(depth, it.level + 2);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint32_t r2 = s2 ? c.right : c.left;
+                if (r2 == NORI_HIP_NO_CHILD) continue;
+                for (int a = 0; a < 3; ++a) { mn[m][a] = s2 ? c.rmin[a] : c.lmin[a]; mx[m][a] = s2 ? c.rmax[a] : c.lmax[a]; }
+                if (r2 & NORI_HIP_LEAF_BIT) ref[m++] = r2;
+                else {
+                    if (!visit(r2)) return fail(NORI_HIP_EINVAL, "node table is not a tree: node " + std::to_string(r2) + " is reached twice");
+                    ref[m++] = (uint32_t) queue.size(); queue.push_back({r2, it.level + 2});
+                }
+            }
+        }
+        const size_t base = out.size(); out.resize(base + 32, 0.f);
+        for (int j = 0; j < 4; ++j) {
+            for (int a = 0; a < 3; ++a) { out[base + 4 * a + j] = mn[j][a]; out[base + 12 + 4 * a + j] = mx[j][a]; }
+            std::memcpy(&out[base + 24 + j], &ref[j], 4);
+        }
+    }
+    root4 = 0;
     return NORI_HIP_OK;
 }
 
@@ -1173,7 +1264,10 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         rc = (e1_ != hipSuccess || e2_ != hipSuccess || e3_ != hipSuccess) ? NORI_HIP_EDEVICE
              : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf, ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->lbvh, lerr);
         hipFree(tmp_prims); hipFree(tmp_shade);
-        if (rc) { ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
+        if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
+        ctx->d_nodes4 = (float4 *) ctx->lbvh.nodes4; ctx->n_nodes4 = ctx->lbvh.n_nodes4; ctx->lbvh.nodes4 = nullptr;
+        // up to three stack entries per four-box level: deeper trees are walked through their two-box nodes
+        if (3u * ((ctx->lbvh.depth + 1u) / 2u) > (uint32_t) (ND_STACK - 2)) { hipFree(ctx->d_nodes4); ctx->d_nodes4 = nullptr; ctx->n_nodes4 = 0; }
         root = ctx->lbvh.root;
         for (int i = 0; i < 3; ++i) { root_min[i] = ctx->lbvh.root_min[i]; root_max[i] = ctx->lbvh.root_max[i]; }
     } else {
@@ -1196,6 +1290,14 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
             root = new_of[d->root];
         }
         if ((rc = upload(ctx->d_nodes, nodes.data(), d->n_nodes))) return rc;
+        std::vector<float> wide; uint32_t root4w = root, depth = 0;
+        if ((rc = collapse_host(nodes, root, wide, root4w, depth))) return rc;
+        if (depth > (uint32_t) (ND_STACK - 2)) return fail(NORI_HIP_EINVAL, "tree depth " + std::to_string(depth) + " exceeds the traversal stack (" + std::to_string(ND_STACK - 2) + ")");
+        if (!wide.empty() && 3u * ((depth + 1u) / 2u) <= (uint32_t) (ND_STACK - 2)) {
+            float *w = nullptr;
+            if ((rc = upload(w, wide.data(), wide.size()))) return rc;
+            ctx->d_nodes4 = (float4 *) w; ctx->n_nodes4 = (uint32_t) (wide.size() / 32);
+        }
     }
     if (!device_build) {
         if ((rc = upload(ctx->d_prims, d->prims, d->n_prims))) return rc;
@@ -1213,7 +1315,8 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
     sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
     // a device-built tree has no reference child order to keep: the nearer child is entered first
-    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = (ctx->ordered || device_build) ? 1 : 0;
+    sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u;
+    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = ((ctx->ordered || device_build) ? 1 : 0) | (ctx->any_near ? 2 : 0);
     for (int i = 0; i < 3; ++i) { sc.root_min[i] = root_min[i]; sc.root_max[i] = root_max[i]; }
     sc.cam = d->camera;
     sc.inv_w = 1.0f / (float) d->camera.width; sc.inv_h = 1.0f / (float) d->camera.height;
@@ -1425,14 +1528,16 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     // the trace stages give every wave a static share of the pool, so all their workgroups must be resident at once.
     // LDS of a workgroup: stacks + staging buffers of its waves, the rest of its share caches the top of the tree.
     const unsigned trace_threads = (unsigned) ctx->trace_threads, trace_nw = trace_threads / 64;
-    const size_t trace_fixed = (size_t) trace_nw * (TRACE_DEPTH * 64 * 8 + 64 * 52);      // stacks + staged rays (origin, direction, reciprocal direction, slot)
+    const bool wide = ctx->wide && ctx->d_nodes4 != nullptr && ctx->merge_trace;          // the merged trace stage over four-box nodes
+    const int trace_waves = wide ? ND_WIDE_WAVES : 6;                                     // waves per SIMD the kernel is built for
+    const size_t trace_fixed = wide ? ctx->trace_lds_wide : ctx->trace_lds;               // stacks + staged rays (origin, direction, reciprocal direction, slot)
     int trace_bpc = ctx->trace_blocks_per_cu;
-    if (trace_bpc == 0) trace_bpc = std::max(1, std::min<int>((int) (6 * 4 / trace_nw), (int) (163840 / trace_fixed)));      // 6 waves per SIMD (80 VGPRs)
-    const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (6 * 4 / trace_nw)));     // more workgroups than that run in rounds
+    if (trace_bpc == 0) trace_bpc = std::max(1, std::min<int>((int) (trace_waves * 4 / trace_nw), (int) (163840 / trace_fixed)));
+    const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (trace_waves * 4 / trace_nw)));     // more workgroups than that run in rounds
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
     const unsigned int trace_box2 = (unsigned int) ctx->box2 | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16);
-    const size_t trace_lds = ctx->trace_lds;
+    const size_t trace_lds = trace_fixed;
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
     unsigned trace_blocks = 1, shade_blocks = 1; size_t shade_lds = 0;
     auto shade_run = [](unsigned int slots, unsigned int blocks) { return (((slots + blocks - 1) / blocks) + 255u) & ~255u; };   // = per_block in shade_body
@@ -1462,7 +1567,11 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
 #define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, ((K) == TK_BOTH ? trace_box2 : (trace_box2 & 0xffu)), c)
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
-                if (ctx->spec) {
+                if (wide) {
+                    void (*k4)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *) =
+                        ctx->profile ? (ctx->spec ? k_trace_pool4<true, true> : k_trace_pool4<true, false>) : (ctx->spec ? k_trace_pool4<false, true> : k_trace_pool4<false, false>);
+                    hipLaunchKernelGGL(k4, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
+                } else if (ctx->spec) {
                     if (ctx->profile) hipLaunchKernelGGL((k_trace_pool<TK_BOTH, true, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
                     else hipLaunchKernelGGL((k_trace_pool<TK_BOTH, false, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
                 } else if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);

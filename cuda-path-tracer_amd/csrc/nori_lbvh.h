@@ -16,6 +16,8 @@ struct Result {
     uint32_t n_used, depth;        // = n_nodes; depth of the uncollapsed tree (levels of inner nodes)
     float root_min[3], root_max[3];
     double build_ms;               // device time of the whole build (HIP events)
+    void *nodes4 = nullptr;        // the same tree as 128-byte four-box nodes (Trav::box_step4), hipMalloc'ed here, owned by the caller;
+    uint32_t n_nodes4 = 0;         // null when the tree is one leaf.  Its root is node 0.
 };
 
 // prims_in / shade_in: n records in any order (bit 31 of shape_flags ignored).  prims_out / shade_out: n records in

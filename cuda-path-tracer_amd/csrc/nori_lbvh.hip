@@ -219,6 +219,45 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t n_inner, const uint32_
 
 __global__ void k_mark_last(NoriHipPrim *pout, uint32_t pos) { pout[pos].shape_flags |= 0x80000000u; }
 
+// ---- four-box nodes (Trav::box_step4 in nori_device.h): every inner node at an even depth becomes a 128-byte node holding its
+// grandchildren (a child that is a leaf stays a child).  Works on the emitted nodes before they are packed.
+__global__ __launch_bounds__(256) void k_even(uint32_t n_inner, const uint32_t *used, const uint32_t *parent_inner, uint32_t *even) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    uint32_t d = 0;
+    if (used[i]) for (uint32_t cur = i; cur != 0u; cur = parent_inner[cur]) ++d;
+    even[i] = (used[i] && !(d & 1u)) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_collapse4(uint32_t n_inner, const uint32_t *even, const uint32_t *widx, const NoriHipNode *nodes, float4 *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner || !even[i]) return;
+    const float inf = __builtin_huge_valf();
+    float mn[4][3], mx[4][3]; uint32_t ref[4]; int m = 0;
+    for (int k = 0; k < 4; ++k) { ref[k] = NORI_HIP_NO_CHILD; for (int a = 0; a < 3; ++a) { mn[k][a] = inf; mx[k][a] = -inf; } }
+    const NoriHipNode w = nodes[i];
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t r = side ? w.right : w.left;
+        if (r == NORI_HIP_NO_CHILD) continue;
+        if (r & LB_LEAF) {
+            for (int a = 0; a < 3; ++a) { mn[m][a] = side ? w.rmin[a] : w.lmin[a]; mx[m][a] = side ? w.rmax[a] : w.lmax[a]; }
+            ref[m++] = r;
+        } else {
+            const NoriHipNode c = nodes[r];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint32_t r2 = s2 ? c.right : c.left;
+                if (r2 == NORI_HIP_NO_CHILD) continue;
+                for (int a = 0; a < 3; ++a) { mn[m][a] = s2 ? c.rmin[a] : c.lmin[a]; mx[m][a] = s2 ? c.rmax[a] : c.lmax[a]; }
+                ref[m++] = (r2 & LB_LEAF) ? r2 : widx[r2];
+            }
+        }
+    }
+    float4 *q = out + 8 * (size_t) widx[i];
+    q[0] = make_float4(mn[0][0], mn[1][0], mn[2][0], mn[3][0]); q[1] = make_float4(mn[0][1], mn[1][1], mn[2][1], mn[3][1]); q[2] = make_float4(mn[0][2], mn[1][2], mn[2][2], mn[3][2]);
+    q[3] = make_float4(mx[0][0], mx[1][0], mx[2][0], mx[3][0]); q[4] = make_float4(mx[0][1], mx[1][1], mx[2][1], mx[3][1]); q[5] = make_float4(mx[0][2], mx[1][2], mx[2][2], mx[3][2]);
+    q[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+    q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 } // namespace
 
 // The order of the key bits decides which axis the radix tree splits at each level.  A plain Morton code alternates x, y, z
@@ -340,6 +379,24 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
     LCHK(alloc(&scan_tmp, scan_bytes));
     LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, used, new_index, (int) ni, stream));
     hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) used, (const uint32_t *) new_index, (const NoriHipNode *) nodes_tmp, nodes_out);
+    LCHK(hipGetLastError());
+    // the same tree as four-box nodes
+    uint32_t *even, *widx;
+    LCHK(alloc((void **) &even, ni * 4)); LCHK(alloc((void **) &widx, ni * 4));
+    hipLaunchKernelGGL(k_even, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) used, (const uint32_t *) parent_inner, even);
+    LCHK(hipGetLastError());
+    LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, even, widx, (int) ni, stream));
+    uint32_t h_w[2];
+    LCHK(hipMemcpyAsync(&h_w[0], even + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
+    LCHK(hipMemcpyAsync(&h_w[1], widx + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
+    LCHK(hipStreamSynchronize(stream));
+    res.n_nodes4 = h_w[0] + h_w[1];
+    {
+        void *n4 = nullptr;
+        LCHK(hipMalloc(&n4, (size_t) std::max<uint32_t>(res.n_nodes4, 1u) * 128));       // owned by the caller from here on
+        res.nodes4 = n4;
+    }
+    hipLaunchKernelGGL(k_collapse4, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) even, (const uint32_t *) widx, (const NoriHipNode *) nodes_tmp, (float4 *) res.nodes4);
     LCHK(hipGetLastError());
     uint32_t h_last[2];
     LCHK(hipMemcpyAsync(&h_last[0], used + (ni - 1), 4, hipMemcpyDeviceToHost, stream));

@@ -228,7 +228,9 @@ class Context:
 
     def trace_kernel_name(self):
         """the kernel bench.py's roofline is quoted on (the trace stage of the wavefront pipeline)"""
-        return "k_trace_pool<TK_BOTH>" if os.environ.get("NORI_HIP_MERGE", "1") != "0" else "k_trace_pool<TK_EXTEND>"
+        if os.environ.get("NORI_HIP_MERGE", "1") == "0":
+            return "k_trace_pool<TK_EXTEND>"
+        return "k_trace_pool4" if os.environ.get("NORI_HIP_WIDE", "1") != "0" else "k_trace_pool<TK_BOTH>"
 
     def clear_film(self):
         _hchk(self.L.nori_hip_clear_film(self.h))
