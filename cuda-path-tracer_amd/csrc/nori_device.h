@@ -428,6 +428,27 @@ __device__ __forceinline__ bool trace(const DevScene &sc, const Ray &ray_in, Hit
     return trace<ANY>(sc, g, ray_in, hit, stk, n_nodes, n_prims);
 }
 
+// the same loop over the four-box nodes (sc.nodes4 must not be null)
+template <bool ANY, typename StackT>
+__device__ __forceinline__ bool trace4(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
+    Trav<ANY> tv;
+    const bool ordered = (ANY && (sc.ordered & 2)) || (sc.ordered & 1);
+    if (tv.begin(sc, ray_in, n_nodes)) tv.cur = sc.root4;
+    for (;;) {
+        const unsigned long long m_in = __ballot(tv.at_inner());
+        if (m_in) {
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step4_fast(sc.nodes4, stk, ordered); }
+            else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step4(sc.nodes4, stk, ordered); else n_nodes += tv.box_step4_fast(sc.nodes4, stk, ordered); }
+        }
+        const unsigned long long m_lf = __ballot(tv.at_leaf());
+        if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) { if (tv.at_leaf()) tv.prim_step(sc, n_prims); }
+        if (tv.at_pop()) tv.pop_step(stk);
+        if (__ballot(!tv.done()) == 0ull) break;
+    }
+    hit = tv.hit;
+    return tv.found;
+}
+
 // per-lane stack in private (scratch) memory
 struct ScratchStack {
     uint2 e[ND_STACK];

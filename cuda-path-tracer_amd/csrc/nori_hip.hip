@@ -339,6 +339,33 @@ __device__ __forceinline__ F3 add_pending_nee(F3 li, unsigned int flags, float4 
     return li;
 }
 
+// Ray ordering.  After a few bounces the rays of neighbouring slots have nothing to do with each other, and on a scene whose
+// tree does not fit the caches every lane of a wave then drags its own lines through L2.  Before the trace stage the slots are
+// sorted by the cell of their path vertex (30-bit Morton code of the extend ray's origin in the root box, which is also where
+// the slot's shadow ray ends), and the trace stage takes its batches through that order: the rays of a wave start (or end) in the
+// same corner of the tree and share the nodes and records there.  Only the order of the work changes, no ray and no result.
+__device__ __forceinline__ unsigned int spread10(unsigned int x) {
+    x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_ray_keys(DevScene sc, Pool pool, unsigned int n_slots, unsigned int *keys, unsigned int *ids) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const float4 o = pool.ray_o[i], d = pool.ray_d[i], sd = pool.sh_d[i], so = pool.sh_o[i];
+    const bool ext = !(d.w < o.w), sh = !(sd.w < so.w);
+    unsigned int key = 0x3fffffffu;                                       // no ray in the slot: last
+    if (ext || sh) {
+        // the path vertex: the extend ray's origin, or (the path ends here) the far end of the shadow ray
+        const float px = ext ? o.x : so.x + sd.w * sd.x, py = ext ? o.y : so.y + sd.w * sd.y, pz = ext ? o.z : so.z + sd.w * sd.z;
+        const float ex = sc.root_max[0] - sc.root_min[0], ey = sc.root_max[1] - sc.root_min[1], ez = sc.root_max[2] - sc.root_min[2];
+        const float qx = ex > 0.f ? (px - sc.root_min[0]) / ex : 0.f, qy = ey > 0.f ? (py - sc.root_min[1]) / ey : 0.f, qz = ez > 0.f ? (pz - sc.root_min[2]) / ez : 0.f;
+        const unsigned int ix = (unsigned int) fminf(fmaxf(qx * 1024.f, 0.f), 1023.f), iy = (unsigned int) fminf(fmaxf(qy * 1024.f, 0.f), 1023.f), iz = (unsigned int) fminf(fmaxf(qz * 1024.f, 0.f), 1023.f);
+        key = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
+        if (key == 0x3fffffffu) key = 0x3ffffffeu;
+    }
+    keys[i] = key; ids[i] = i;
+}
+
 // Shade stage.  Each block owns a contiguous run of slots:
 //   pass A  shades (see above); a slot whose path goes on is appended to the block's keep list, a slot that is free
 //           afterwards to its regenerate list (both in LDS: one array of 16-bit offsets into the run, the regenerate
@@ -532,7 +559,7 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 #define ND_WIDE_WAVES 5         /* waves per SIMD the four-box trace stage is built for */
 #endif
 template <int KIND, bool PROF, bool SPEC, bool WIDE>
-__device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
+__device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
     constexpr int DEPTH = WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
     extern __shared__ float4 dyn_lds[];
@@ -558,6 +585,7 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
     bool dyn_asked = false; unsigned int dyn_idx = 0u;                   // a cursor has been asked for; lane 0 holds the answer
     bool loading = false;                                                // wave-uniform: lo4/ld4 hold a batch in flight
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
+    unsigned int l_slot = 0;                                             // the slot of this lane's ray of the batch in flight
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
     uint2 stack_spill[ND_STACK - DEPTH];
     LdsStackT<DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + wv * (DEPTH * 64) + lane;
@@ -588,8 +616,8 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
                 Ray r; r.o = f3(lo4.x, lo4.y, lo4.z); r.mint = lo4.w; r.d = f3(ld4.x, ld4.y, ld4.z); r.maxt = ld4.w;
                 enters = tb.begin(sc, r, root_tested);
                 if (!enters) {
-                    if ((KIND == TK_BOTH) ? l_any : ANY) reinterpret_cast<float *>(pool.sh_c + l_base + lane)[3] = 1.0f;
-                    else pool.hit[l_base + lane] = make_uint4(0xffffffffu, __float_as_uint(ND_INF), 0u, 0u);
+                    if ((KIND == TK_BOTH) ? l_any : ANY) reinterpret_cast<float *>(pool.sh_c + l_slot)[3] = 1.0f;
+                    else pool.hit[l_slot] = make_uint4(0xffffffffu, __float_as_uint(ND_INF), 0u, 0u);
                 }
             }
             n_boxes += (unsigned int) __popcll(__ballot(root_tested != 0u));
@@ -598,7 +626,7 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
             if (enters) {
                 const unsigned int r = __builtin_amdgcn_mbcnt_hi((unsigned int) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m, 0u));
                 st_o[r] = make_float4(lo4.x, lo4.y, lo4.z, tb.mint); st_d[r] = ld4; st_r[r] = make_float4(tb.rcp.x, tb.rcp.y, tb.rcp.z, 0.f);
-                st_slot[r] = (l_base + lane) | ((KIND == TK_BOTH && l_any) ? 0x80000000u : 0u) | (tb.special ? 0x40000000u : 0u);
+                st_slot[r] = l_slot | ((KIND == TK_BOTH && l_any) ? 0x80000000u : 0u) | (tb.special ? 0x40000000u : 0u);
             }
             s_n = (unsigned int) __popcll(m); s_pos = 0; loading = false;
         }
@@ -620,9 +648,13 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
         if (b_take != 0xffffffffu) {
             l_any = (KIND == TK_BOTH) ? (b_take < nb_pool) : ANY;
             l_base = ((KIND == TK_BOTH && !l_any) ? b_take - nb_pool : b_take) << 6;
-            const unsigned int sl = l_base + lane;
-            if (sl < n_slots) { lo4 = l_any ? pool.sh_o[sl] : pool.ray_o[sl]; ld4 = l_any ? pool.sh_d[sl] : pool.ray_d[sl]; }
-            else { lo4 = make_float4(0.f, 0.f, 0.f, 0.f); ld4 = make_float4(0.f, 0.f, 0.f, -1.f); }
+            const unsigned int pos = l_base + lane;
+            if (pos < n_slots) {
+                // (through the sorted order the slot number is one more dependent load; it is issued a batch ahead like the ray itself)
+                const unsigned int sl = order ? order[pos] : pos;
+                l_slot = sl;
+                lo4 = l_any ? pool.sh_o[sl] : pool.ray_o[sl]; ld4 = l_any ? pool.sh_d[sl] : pool.ray_d[sl];
+            } else { l_slot = 0u; lo4 = make_float4(0.f, 0.f, 0.f, 0.f); ld4 = make_float4(0.f, 0.f, 0.f, -1.f); }
             loading = true;
         }
         // ---- retire finished rays, hand out staged ones
@@ -726,19 +758,19 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
 
 template <int KIND, bool PROF, bool SPEC = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
-    trace_pool_body<KIND, PROF, SPEC, false>(sc, pool, n_slots, stats, thr, box2_lanes, cnt);
+    trace_pool_body<KIND, PROF, SPEC, false>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, nullptr);
 }
 // the merged trace stage over four-box nodes
 template <bool PROF, bool SPEC>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
-    trace_pool_body<TK_BOTH, PROF, SPEC, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt);
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
+    trace_pool_body<TK_BOTH, PROF, SPEC, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
 }
 
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
 // stage launch per bounce would be mostly launch latency.  Persistent waves run the surviving paths of the live
 // list to their end, one bounce per loop trip (shade -> shadow -> extend in registers); wave w of W takes the
 // 64-entry batches w, w+W, ... and a lane whose path has ended takes the next entry of the wave's batch.
-template <bool EXT>
+template <bool EXT, bool WIDE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
     __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
     const unsigned int n = CN_LIVE(cnt);
@@ -789,10 +821,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
             if (so.has_shadow) {
                 Hit sh; ctr.shadow++;
-                if (!trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims)) ps.li = ps.li + so.contrib;
+                if (!(WIDE ? trace4<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims))) ps.li = ps.li + so.contrib;
             }
             bool go_on = !so.end;
-            if (go_on) { ctr.closest++; go_on = trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims); }
+            if (go_on) { ctr.closest++; go_on = WIDE ? trace4<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims) : trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims); }
             if (!go_on) {
                 const unsigned int pxy = __float_as_uint(P.z);
                 if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
@@ -972,6 +1004,7 @@ struct NoriHipContext {
     hipStream_t stream = nullptr;
     bool have_scene = false;
     DevScene sc;
+    uint32_t n_prims = 0, n_nodes = 0;
     float4 *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;     // the tree as 128-byte four-box nodes (null: one-leaf tree, or too deep for the stack)
     bool wide = true;                 // NORI_HIP_WIDE=0: the trace stage walks the 64-byte two-box nodes
     size_t trace_lds_wide = 0;
@@ -982,7 +1015,7 @@ struct NoriHipContext {
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
     int integrator = NORI_HIP_INTEGRATOR_PATH_MIS;   // nori_hip_set_integrator
     lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
-    uint32_t lbvh_leaf = 3;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF; measured: 2-3 best on every workload)
+    uint32_t lbvh_leaf = 0;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF); 0 = 3, or 2 from a million records on (measured)
     bool lbvh_plain = false;          // NORI_HIP_LBVH_MORTON=plain: x, y, z interleaved bit by bit instead of the planned bit order
     float lbvh_big = 0.25f;           // records longer than this fraction of the scene get their own subtree (NORI_HIP_LBVH_BIG, 0 = off)
     float4 *d_film = nullptr; int film_rows = 0, film_cols = 0, border = 0;
@@ -995,6 +1028,8 @@ struct NoriHipContext {
     // wavefront pipeline
     unsigned int pool_slots = 0; Pool pool, pool_b; void *pool_mem = nullptr;     // pool_b: half the slots, for the compaction of the tail
     unsigned int pool_alloc = 0;      // slots the allocated pool holds
+    unsigned int *d_sort = nullptr; size_t sort_temp_bytes = 0;   // keys | keys' | slot numbers | slot numbers' (pool_alloc each) | sort workspace
+    int sort_rays = -1;               // NORI_HIP_SORT: 1 / 0 = order the rays before every trace launch or never; -1 = when the tree does not fit the caches
     bool compact = true;              // NORI_HIP_COMPACT=0: never pack the pool (the tail then sweeps dead slots until k_finish takes over)
     unsigned int *d_qlive = nullptr; WfCounters *d_cnt = nullptr;
     unsigned int *h_ring = nullptr; hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1015,10 +1050,11 @@ struct NoriHipContext {
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
     float *scratch_ptr = nullptr;     // this device's copy of `scratch` (nori_hip_filter_noalloc)
     size_t trace_lds = 0;             // dynamic LDS of a trace-stage workgroup (set once, with the kernels' attribute, in nori_hip_create)
-    bool spec = true;                 // NORI_HIP_SPEC=0: no speculative traversal in the merged trace stage
+    int spec = -1;                    // NORI_HIP_SPEC: 1 / 0 = speculative traversal in the merged trace stage or not; -1 = unless the tree does not fit the
+                                      // caches (there the stage waits for HBM lines, and the extra boxes that speculation lets pass cost more than the waiting it saves)
     int dyn_tries = 3;                // NORI_HIP_DYN_TRIES: queues a finishing wave tries (1..8)
     int dyn_pct = 15;                 // NORI_HIP_DYN: percent of the trace stage's rounds of batches that are handed out dynamically at the end
-    int box2 = 36;                    // NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
+    int box2 = -1;                    // (-1 = 36, or 0 when the tree does not fit the caches) NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 1, thr_prim = 1, thr_refill = 12;   // k_trace_pool step thresholds (lanes), NORI_HIP_THR
@@ -1081,8 +1117,9 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_LBVH_BIG")) { float v = (float) atof(e); if (v >= 0.f) c->lbvh_big = v; }
     if (const char *e = getenv("NORI_HIP_LBVH_MORTON")) c->lbvh_plain = std::string(e) == "plain";
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
-    if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0;
+    if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("NORI_HIP_WIDE")) c->wide = atoi(e) != 0;
+    if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
     if (const char *e = getenv("NORI_HIP_DYN")) { int v = atoi(e); if (v >= 0 && v <= 90) c->dyn_pct = v; }
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
@@ -1133,7 +1170,7 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ctx->free_scene();
     hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_tiles); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
-    hipFree(ctx->d_qlive); hipFree(ctx->d_filt);
+    hipFree(ctx->d_qlive); hipFree(ctx->d_filt); hipFree(ctx->d_sort);
     if (ctx->h_ring) hipHostFree(ctx->h_ring);
     for (int i = 0; i < 4; ++i) if (ctx->ring_ev[i]) hipEventDestroy(ctx->ring_ev[i]);
     for (hipEvent_t e : ctx->ext_ev) hipEventDestroy(e);
@@ -1262,7 +1299,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         hipError_t e3_ = hipMalloc((void **) &ctx->d_nodes, (size_t) std::max<uint32_t>(d->n_prims - 1, 1u) * sizeof(NoriHipNode));
         std::string lerr;
         rc = (e1_ != hipSuccess || e2_ != hipSuccess || e3_ != hipSuccess) ? NORI_HIP_EDEVICE
-             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf, ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->lbvh, lerr);
+             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf ? ctx->lbvh_leaf : (d->n_prims >= 1000000u ? 2u : 3u), ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->lbvh, lerr);
         hipFree(tmp_prims); hipFree(tmp_shade);
         if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
         ctx->d_nodes4 = (float4 *) ctx->lbvh.nodes4; ctx->n_nodes4 = ctx->lbvh.n_nodes4; ctx->lbvh.nodes4 = nullptr;
@@ -1309,7 +1346,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     if ((rc = upload(ctx->d_cdf, d->cdf, d->n_cdf))) return rc;
     if ((rc = upload(ctx->d_textures, d->textures, d->n_textures))) return rc;
     if ((rc = upload(ctx->d_tex_data, d->tex_data, d->n_textures ? (size_t) d->n_tex_bytes : 0))) return rc;
-    ctx->ext = ext;
+    ctx->ext = ext; ctx->n_prims = d->n_prims; ctx->n_nodes = device_build ? ctx->lbvh.n_nodes : d->n_nodes;
     DevScene &sc = ctx->sc;
     sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
@@ -1501,9 +1538,15 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     // ---- wavefront stages over a pool of path slots
     // The pool is sized for the call (a quarter of its paths, between 1 M and 8 M slots, or NORI_HIP_POOL) and allocated when a
     // call needs more slots than the context holds; pool, half-size pool and live list are committed to the context together.
+    // "big tree": nodes and records against the Infinity Cache (256 MiB).  Beyond it the trace stage waits for HBM lines instead of
+    // issuing, and a few defaults change with that (measured on the 10 M-triangle workload): rays are ordered before every trace
+    // launch, no speculative traversal, no second box step per trip, and half instead of a quarter of the call's paths in the pool
+    // (fewer, larger launches: the stage's ramp-up and drain are paid less often).
+    const size_t tree_bytes = (size_t) (ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
+    const bool big_tree = tree_bytes > ((size_t) 192 << 20);
     const unsigned int pool_cap = ctx->pool_slots ? ctx->pool_slots : (1u << 23);
     unsigned int P = pool_cap;
-    if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, (job.total / 4 + 65535) & ~65535ull));
+    if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, (job.total / (big_tree ? 2 : 4) + 65535) & ~65535ull));
     if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
     if (!ctx->pool_mem || ctx->pool_alloc < P) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1512,7 +1555,12 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         DevBufs guard; float4 *mem = nullptr; unsigned int *ql = nullptr;
         HIPCHK(guard.get(mem, (PA + PB) * 10 * sizeof(float4)));
         HIPCHK(guard.get(ql, PA * 4));
-        guard.owned.clear();                                                   // both succeeded: the context owns them now
+        // ray ordering (k_ray_keys + radix sort): two key and two slot-number arrays and the sort's workspace
+        hipFree(ctx->d_sort); ctx->d_sort = nullptr;
+        unsigned int *srt = nullptr; const size_t tb = (lbvh::sort_pairs_temp_bytes((uint32_t) PA) + 255) & ~(size_t) 255;
+        HIPCHK(guard.get(srt, PA * 16 + tb));
+        ctx->d_sort = srt; ctx->sort_temp_bytes = tb;
+        guard.owned.clear();                                                   // all succeeded: the context owns them now
         ctx->pool_mem = mem; ctx->d_qlive = ql; ctx->pool_alloc = (unsigned int) PA;
         auto carve = [](Pool &pl, float4 *base, size_t n) {
             pl.ray_o = base; pl.ray_d = base + n; pl.hit = (uint4 *) (base + 2 * n); pl.thr = base + 3 * n; pl.li = base + 4 * n;
@@ -1529,6 +1577,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     // LDS of a workgroup: stacks + staging buffers of its waves, the rest of its share caches the top of the tree.
     const unsigned trace_threads = (unsigned) ctx->trace_threads, trace_nw = trace_threads / 64;
     const bool wide = ctx->wide && ctx->d_nodes4 != nullptr && ctx->merge_trace;          // the merged trace stage over four-box nodes
+    // the scene's tree and records against the 256 MiB of Infinity Cache: beyond that, ordering the rays pays for its sort
+    const bool sort_rays = ctx->sort_rays < 0 ? big_tree : ctx->sort_rays != 0;
     const int trace_waves = wide ? ND_WIDE_WAVES : 6;                                     // waves per SIMD the kernel is built for
     const size_t trace_fixed = wide ? ctx->trace_lds_wide : ctx->trace_lds;               // stacks + staged rays (origin, direction, reciprocal direction, slot)
     int trace_bpc = ctx->trace_blocks_per_cu;
@@ -1536,7 +1586,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (trace_waves * 4 / trace_nw)));     // more workgroups than that run in rounds
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
-    const unsigned int trace_box2 = (unsigned int) ctx->box2 | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16);
+    const unsigned int trace_box2 = (unsigned int) (ctx->box2 >= 0 ? ctx->box2 : (big_tree ? 0 : 36)) | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16);
+    const bool spec = ctx->spec >= 0 ? ctx->spec != 0 : !big_tree;
     const size_t trace_lds = trace_fixed;
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
     unsigned trace_blocks = 1, shade_blocks = 1; size_t shade_lds = 0;
@@ -1565,13 +1616,20 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
 // (the cursors of the dynamically handed-out batches are reset once per iteration, by k_iter_begin: only the merged
             // stage, one launch per iteration, uses them)
 #define ND_TRACE(K, PR) hipLaunchKernelGGL((k_trace_pool<K, PR>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, ((K) == TK_BOTH ? trace_box2 : (trace_box2 & 0xffu)), c)
+            const unsigned int *order = nullptr;
+            if (wide && sort_rays) {
+                unsigned int *k0 = ctx->d_sort, *k1 = k0 + ctx->pool_alloc, *v0 = k1 + ctx->pool_alloc, *v1 = v0 + ctx->pool_alloc;
+                hipLaunchKernelGGL(k_ray_keys, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, k0, v0);
+                HIPCHK(lbvh::sort_pairs(ctx->stream, v1 + ctx->pool_alloc, ctx->sort_temp_bytes, k0, k1, v0, v1, P, 30));
+                order = v1;
+            }
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
                 if (wide) {
-                    void (*k4)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *) =
-                        ctx->profile ? (ctx->spec ? k_trace_pool4<true, true> : k_trace_pool4<true, false>) : (ctx->spec ? k_trace_pool4<false, true> : k_trace_pool4<false, false>);
-                    hipLaunchKernelGGL(k4, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
-                } else if (ctx->spec) {
+                    void (*k4)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *, const unsigned int *) =
+                        ctx->profile ? (spec ? k_trace_pool4<true, true> : k_trace_pool4<true, false>) : (spec ? k_trace_pool4<false, true> : k_trace_pool4<false, false>);
+                    hipLaunchKernelGGL(k4, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
+                } else if (spec) {
                     if (ctx->profile) hipLaunchKernelGGL((k_trace_pool<TK_BOTH, true, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
                     else hipLaunchKernelGGL((k_trace_pool<TK_BOTH, false, true>), dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c);
                 } else if (ctx->profile) ND_TRACE(TK_BOTH, true); else ND_TRACE(TK_BOTH, false);
@@ -1598,6 +1656,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
                 const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u)));
                 if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (wide) hipLaunchKernelGGL((k_finish<false, true>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
                 ++it;

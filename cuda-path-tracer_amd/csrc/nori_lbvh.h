@@ -29,4 +29,8 @@ struct Result {
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
           NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, Result &res, std::string &err);
 
+// radix sort of n (key, value) pairs of 32 bits each on key bits [0, end_bit); `temp` of sort_pairs_temp_bytes(n) bytes
+size_t sort_pairs_temp_bytes(uint32_t n);
+hipError_t sort_pairs(hipStream_t stream, void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, int end_bit);
+
 } // namespace lbvh

@@ -414,4 +414,14 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
 #undef LCHK
 }
 
+// radix sort of (32-bit key, 32-bit value) pairs on `stream` (hipCUB); the render loop orders its rays with it
+size_t sort_pairs_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void) hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr, (uint32_t *) nullptr, (int) n, 0, 32, (hipStream_t) nullptr);
+    return bytes;
+}
+hipError_t sort_pairs(hipStream_t stream, void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, int end_bit) {
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int) n, 0, end_bit, stream);
+}
+
 } // namespace lbvh

@@ -194,7 +194,9 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_DYN="0"),                                  # all batches dealt statically
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_DYN="90", NORI_HIP_DYN_TRIES="1", NORI_HIP_POOL="70000"),   # nearly all from the queues, own queue only
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_DYN="50", NORI_HIP_DYN_TRIES="8", NORI_HIP_POOL="1000")]    # a grid of fewer than 8 workgroups
-    configs += [dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0"),                                 # trace stage over the 64-byte two-box nodes
+    configs += [dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1"),                                 # rays ordered by the cell of their path vertex
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_POOL="1000", NORI_HIP_FINISH="1"),
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0"),                                 # trace stage over the 64-byte two-box nodes
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0", NORI_HIP_SPEC="0", NORI_HIP_POOL="4096")]
     # Any-hit rays normally enter the nearer child first (the answer does not depend on the order, the number of records tested
     # before an occluder is found does, and the nearer of two children is not always the nearest of four).  For the record-count
