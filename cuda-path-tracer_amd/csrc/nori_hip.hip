@@ -1083,8 +1083,15 @@ struct NoriHipContext {
 extern "C" {
 
 const char *nori_hip_last_error(void) { return g_err.c_str(); }
+void nori_hip_set_error_(const char *msg) { g_err = msg ? msg : ""; }       // for the library's other translation units (nori_group.hip)
 
 static int create_impl(NoriHipContext *c, int device);
+
+int nori_hip_device_count(int *n) {
+    if (!n) return fail(NORI_HIP_EINVAL, "null argument");
+    HIPCHK(hipGetDeviceCount(n));
+    return NORI_HIP_OK;
+}
 
 int nori_hip_create(int device, NoriHipContext **out) {
     if (!out) return fail(NORI_HIP_EINVAL, "out is null");

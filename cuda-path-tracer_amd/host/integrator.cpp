@@ -15,15 +15,32 @@ static void hipCheck(int rc, const char *what) {
 }
 
 /// GPU path tracer with multiple importance sampling.  Registered as "path_mis" (so existing scene files select
-/// it unchanged) and as "path_mis_hip".  Properties: device (int, default 0 or $NORI_HIP_DEVICE); bvh (string, "host" =
-/// the reference's SAH tree built by Scene::activate (default) or "device" = a linear BVH built on the GPU at preprocess(),
-/// default $NORI_HIP_BVH); film (string, "reference" = this fork's single-pixel ImageBlock::put (default) or "splat" = upstream
-/// Nori's reconstruction-filter splat, default $NORI_HIP_FILM).
+/// it unchanged) and as "path_mis_hip".  Properties: device (int, default 0 or $NORI_HIP_DEVICE); devices (string, default
+/// $NORI_HIP_DEVICES: "all" or a comma-separated list such as "0,1,2,3" - the integrator then drives one context per listed GPU
+/// through nori_hip_group_*, splits every render call among them and sums the films with RCCL; `device` is ignored);
+/// partition (string, "spp" (default) or "tiles", default $NORI_HIP_PARTITION: how a group splits a render call);
+/// bvh (string, "host" = the reference's SAH tree built by Scene::activate (default) or "device" = the tree built on the GPU at
+/// preprocess(), default $NORI_HIP_BVH); film (string, "reference" = this fork's single-pixel ImageBlock::put (default) or
+/// "splat" = upstream Nori's reconstruction-filter splat, default $NORI_HIP_FILM).
 class PathMisHip : public GpuIntegrator {
 public:
     explicit PathMisHip(const PropertyList &props, int kind = NORI_HIP_INTEGRATOR_PATH_MIS) : m_kind(kind) {
         const char *env = getenv("NORI_HIP_DEVICE");
         m_device = props.getInteger("device", env ? atoi(env) : 0);
+        const char *denv = getenv("NORI_HIP_DEVICES");
+        const std::string devs = props.getString("devices", denv ? denv : "");
+        if (devs == "all") m_allDevices = true;
+        else if (!devs.empty()) {
+            for (const std::string &t : tokenize(devs, ", ")) {
+                char *end = nullptr; long v = strtol(t.c_str(), &end, 10);
+                if (end == t.c_str() || *end || v < 0) throw NoriException::format("path_mis: bad entry \"%s\" in devices", t.c_str());
+                m_devices.push_back((int) v);
+            }
+        }
+        const char *penv = getenv("NORI_HIP_PARTITION");
+        const std::string part = props.getString("partition", penv ? penv : "spp");
+        if (part != "spp" && part != "tiles") throw NoriException::format("path_mis: unknown partition \"%s\" (spp, tiles)", part.c_str());
+        m_partition = part == "tiles" ? NORI_HIP_PARTITION_TILES : NORI_HIP_PARTITION_SPP;
         const char *benv = getenv("NORI_HIP_BVH");
         std::string bvh = props.getString("bvh", benv ? benv : "host");
         if (bvh != "host" && bvh != "device") throw NoriException::format("path_mis: unknown bvh mode \"%s\" (host, device)", bvh.c_str());
@@ -34,27 +51,45 @@ public:
         m_splat = film == "splat";
     }
     bool buildsOwnBVH() const override { return m_deviceBvh; }
-    ~PathMisHip() override { if (m_ctx) nori_hip_destroy(m_ctx); }
+    ~PathMisHip() override { if (m_group) nori_hip_group_destroy(m_group); else if (m_ctx) nori_hip_destroy(m_ctx); }
     void preprocess(const Scene *scene) override {
         flattenScene(scene, m_flat);
         if (m_flat.desc.n_emitters == 0 && m_kind == NORI_HIP_INTEGRATOR_PATH_MIS) throw NoriException("path_mis: the scene has no emitters");
+        const bool grouped = m_allDevices || !m_devices.empty();
+        if (grouped && !m_group) {
+            if (m_allDevices) {
+                int n = 0; hipCheck(nori_hip_device_count(&n), "nori_hip_device_count");
+                m_devices.clear(); for (int i = 0; i < n; ++i) m_devices.push_back(i);
+            }
+            hipCheck(nori_hip_group_create(m_devices.data(), (int) m_devices.size(), &m_group), "nori_hip_group_create");
+            m_ctx = nori_hip_group_context(m_group, 0);
+        }
         if (!m_ctx) hipCheck(nori_hip_create(m_device, &m_ctx), "nori_hip_create");
-        hipCheck(nori_hip_set_integrator(m_ctx, m_kind), "nori_hip_set_integrator");
+        float table[33]; float radius = 0.f;
         if (m_splat) {
             // film = "splat": upstream Nori's filter-weighted accumulation; the table is ImageBlock::init's (src/block.cpp:54-64)
             const ReconstructionFilter *rf = scene->getCamera()->getReconstructionFilter();
-            float table[33]; const float radius = rf->getRadius();
+            radius = rf->getRadius();
             for (int i = 0; i < 32; ++i) table[i] = rf->eval((radius * i) / 32);
             table[32] = 0.0f;
-            hipCheck(nori_hip_set_film_filter(m_ctx, table, radius), "nori_hip_set_film_filter");
-        } else hipCheck(nori_hip_set_film_filter(m_ctx, nullptr, 0.f), "nori_hip_set_film_filter");
+        }
+        if (m_group) {
+            hipCheck(nori_hip_group_set_integrator(m_group, m_kind), "nori_hip_group_set_integrator");
+            hipCheck(nori_hip_group_set_film_filter(m_group, m_splat ? table : nullptr, radius), "nori_hip_group_set_film_filter");
+            hipCheck(nori_hip_group_upload_scene(m_group, &m_flat.desc, m_deviceBvh ? 1 : 0), "nori_hip_group_upload_scene");
+            return;
+        }
+        hipCheck(nori_hip_set_integrator(m_ctx, m_kind), "nori_hip_set_integrator");
+        hipCheck(nori_hip_set_film_filter(m_ctx, m_splat ? table : nullptr, radius), "nori_hip_set_film_filter");
         if (m_deviceBvh) hipCheck(nori_hip_upload_scene_build(m_ctx, &m_flat.desc), "nori_hip_upload_scene_build");
         else hipCheck(nori_hip_upload_scene(m_ctx, &m_flat.desc), "nori_hip_upload_scene");
     }
+    /// Accumulates samples [spp_begin, spp_end) of every pixel into the film (with a group: split among its devices, films summed).
     void render(const Scene *scene, int spp_begin, int spp_end) override {
         if (!m_ctx) preprocess(scene);
         const NoriHipCamera &c = m_flat.desc.camera;
-        hipCheck(nori_hip_render(m_ctx, 0, 0, c.width, c.height, spp_begin, spp_end), "nori_hip_render");
+        if (m_group) hipCheck(nori_hip_group_render(m_group, spp_begin, spp_end, m_partition), "nori_hip_group_render");
+        else hipCheck(nori_hip_render(m_ctx, 0, 0, c.width, c.height, spp_begin, spp_end), "nori_hip_render");
     }
     void readFilm(std::vector<float> &film, int &rows, int &cols, int &border) override {
         need(); hipCheck(nori_hip_film_dims(m_ctx, &rows, &cols, &border), "nori_hip_film_dims");
@@ -65,11 +100,13 @@ public:
         rgb.resize((size_t) c.width * c.height * 3); hipCheck(nori_hip_read_bitmap(m_ctx, rgb.data()), "nori_hip_read_bitmap");
     }
     NoriHipContext *context() override { return m_ctx; }
+    NoriHipGroup *group() { return m_group; }
     const FlatScene &flat() const override { return m_flat; }
     std::string toString() const override { return m_kind == NORI_HIP_INTEGRATOR_PATH_MATS ? "PathMatsIntegrator[backend=hip/gfx950]" : m_kind == NORI_HIP_INTEGRATOR_DIRECT_MIS ? "DirectMisIntegrator[backend=hip/gfx950]" : "PathMisIntegrator[backend=hip/gfx950]"; }
 private:
     void need() const { if (!m_ctx) throw NoriException("path_mis: preprocess() has not run"); }
     int m_kind; int m_device = 0; bool m_deviceBvh = false, m_splat = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
+    bool m_allDevices = false; std::vector<int> m_devices; int m_partition = NORI_HIP_PARTITION_SPP; NoriHipGroup *m_group = nullptr;
 };
 static NoriObject *PathMisHip_create(const PropertyList &l) { return new PathMisHip(l); }
 // "path_mats" (src/pathMatsIntegrator.cpp:87): the same plugin with the other Li

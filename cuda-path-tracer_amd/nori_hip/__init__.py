@@ -96,6 +96,19 @@ def hip_lib():
         L.nori_hip_reset_stats.argtypes = [vp]
         L.nori_hip_stream.argtypes = [vp, C.POINTER(vp)]
         L.nori_hip_synchronize.argtypes = [vp]
+        L.nori_hip_device_count.argtypes = [C.POINTER(i32)]
+        L.nori_hip_group_create.argtypes = [vp, i32, C.POINTER(vp)]
+        L.nori_hip_group_destroy.argtypes = [vp]
+        L.nori_hip_group_size.argtypes = [vp]
+        L.nori_hip_group_context.restype = vp
+        L.nori_hip_group_context.argtypes = [vp, i32]
+        L.nori_hip_group_upload_scene.argtypes = [vp, vp, i32]
+        L.nori_hip_group_set_integrator.argtypes = [vp, i32]
+        L.nori_hip_group_set_film_filter.argtypes = [vp, vp, C.c_float]
+        L.nori_hip_group_clear_film.argtypes = [vp]
+        L.nori_hip_group_render.argtypes = [vp, i32, i32, i32]
+        L.nori_hip_group_reduce_films.argtypes = [vp]
+        L.nori_hip_group_reduce_ms.argtypes = [vp, C.POINTER(C.c_double)]
         _hip = L
     return _hip
 
@@ -286,6 +299,57 @@ class Context:
 
     def synchronize(self):
         _hchk(self.L.nori_hip_synchronize(self.h))
+
+
+PARTITION_SPP, PARTITION_TILES = 0, 1
+
+
+def device_count():
+    n = C.c_int()
+    _hchk(hip_lib().nori_hip_device_count(C.byref(n)))
+    return n.value
+
+
+class Group:
+    """nori_hip_group_*: one context per listed GPU of this node, driven together; films summed with RCCL"""
+
+    def __init__(self, devices):
+        self.L = hip_lib()
+        d = np.ascontiguousarray(devices, np.int32)
+        h = C.c_void_p()
+        _hchk(self.L.nori_hip_group_create(_vp(d), len(d), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.nori_hip_group_destroy(self.h)
+        self.h = None
+
+    def __len__(self):
+        return self.L.nori_hip_group_size(self.h)
+
+    def context(self, i=0):
+        c = self.L.nori_hip_group_context(self.h, i)
+        if not c:
+            raise NoriHipError("no such member")
+        return Context(handle=c, owned=False)
+
+    def upload(self, desc_ptr, build_on_device=False):
+        _hchk(self.L.nori_hip_group_upload_scene(self.h, C.cast(desc_ptr, C.c_void_p), int(build_on_device)))
+
+    def clear_film(self):
+        _hchk(self.L.nori_hip_group_clear_film(self.h))
+
+    def render(self, spp_begin, spp_end, partition=PARTITION_SPP):
+        _hchk(self.L.nori_hip_group_render(self.h, spp_begin, spp_end, partition))
+
+    def reduce_films(self):
+        _hchk(self.L.nori_hip_group_reduce_films(self.h))
+
+    def reduce_ms(self):
+        ms = C.c_double()
+        _hchk(self.L.nori_hip_group_reduce_ms(self.h, C.byref(ms)))
+        return ms.value
 
 
 class HostScene:

@@ -172,6 +172,7 @@ const char *nori_hip_last_error(void);
 
 /* One context per GPU.  Replaces the implicit process-wide state of the reference's renderer
  * (cudaSetDevice(0) in cuda/CudaRender.cpp:17; Scene ownership in src/render.cpp:112-123). */
+int nori_hip_device_count(int *n);
 int nori_hip_create(int device, NoriHipContext **out);
 int nori_hip_destroy(NoriHipContext *ctx);
 
@@ -266,6 +267,35 @@ int nori_hip_reset_stats(NoriHipContext *ctx);
 /* stream the context launches on (hipStream_t as void*), for callers that time or order work around it */
 int nori_hip_stream(NoriHipContext *ctx, void **stream);
 int nori_hip_synchronize(NoriHipContext *ctx);
+
+/*
+ * Several GPUs of one node behind one handle.  No counterpart in the reference, which renders on one device
+ * (cudaSetDevice(0), cuda/CudaRender.cpp:17); this is how a Nori-side caller (the "path_mis" plugin's `devices` property, the
+ * headless CLI) uses the node.  A group owns one context per listed device.  The scene is uploaded to every device;
+ * nori_hip_group_render gives every device its share of samples [spp_begin, spp_end) -
+ *   NORI_HIP_PARTITION_SPP    a contiguous slice of the sample range for the whole image, or
+ *   NORI_HIP_PARTITION_TILES  every n-th band of 32 rows (NORI_BLOCK_SIZE, include/nori/block.h:30), all samples, one pass -
+ * renders them concurrently (one host thread per device) and sums the fp32 films in place with one RCCL all-reduce over xGMI:
+ * ImageBlock::put(ImageBlock&) (src/block.cpp:131-140) across devices.  Afterwards every member's film is the job's film:
+ * read it, or run nori_hip_filter, on nori_hip_group_context(g, 0).  Sample streams are keyed by the global sample index, so
+ * the result does not depend on the number of devices beyond the order of the fp32 sums.  Like nori_hip_render the call
+ * ACCUMULATES: what the films held before it (the sum of earlier group renders) is counted once.  RCCL is loaded when the first
+ * group is created.  A group is driven by one caller at a time.
+ */
+typedef struct NoriHipGroup NoriHipGroup;
+enum { NORI_HIP_PARTITION_SPP = 0, NORI_HIP_PARTITION_TILES = 1 };
+int nori_hip_group_create(const int *devices, int n, NoriHipGroup **out);
+int nori_hip_group_destroy(NoriHipGroup *g);
+int nori_hip_group_size(NoriHipGroup *g);
+NoriHipContext *nori_hip_group_context(NoriHipGroup *g, int i);
+int nori_hip_group_upload_scene(NoriHipGroup *g, const NoriHipSceneDesc *desc, int build_on_device);
+int nori_hip_group_set_integrator(NoriHipGroup *g, int kind);
+int nori_hip_group_set_film_filter(NoriHipGroup *g, const float *table33, float radius);
+int nori_hip_group_clear_film(NoriHipGroup *g);
+int nori_hip_group_render(NoriHipGroup *g, int spp_begin, int spp_end, int partition);
+/* the all-reduce alone (for callers that render on the member contexts themselves), and its device time on the last call */
+int nori_hip_group_reduce_films(NoriHipGroup *g);
+int nori_hip_group_reduce_ms(NoriHipGroup *g, double *ms);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,58 @@
+"""GPU: several devices behind one handle (nori_hip_group_*, the `devices` property of the path_mis plugin).  The box that runs
+these tests has one GPU, so the group has one member: the code path - contexts made by the group, per-device host threads'
+work split, RCCL communicator, in-place all-reduce on the context's stream, accumulation across calls - is the one eight GPUs take."""
+import os
+
+import numpy as np
+import pytest
+
+import nori_hip as NH
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+XML = os.path.join(SCENES, "cbox", "cbox_path_mis.xml")
+
+
+def test_group_of_one_device_renders_reduces_and_accumulates_like_a_context():
+    W, H, spp = 64, 72, 6
+    hs = NH.HostScene(XML, W, H, spp)
+    ctx = hs.preprocess()
+    ctx.clear_film(); ctx.render(0, spp)
+    want = ctx.read_film()
+    g = NH.Group([0])
+    assert len(g) == 1 and NH.device_count() >= 1
+    g.upload(hs.flatten())
+    for part in (NH.PARTITION_SPP, NH.PARTITION_TILES):
+        g.clear_film()
+        g.render(0, 2, part); g.render(2, spp, part)              # two calls accumulate, the earlier sum is counted once
+        got = g.context(0).read_film()
+        assert np.array_equal(got[..., 3], want[..., 3])
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-5)
+        assert g.reduce_ms() >= 0.0
+    # configs[4]'s order of operations: render slices, reduce, then the filter pass on member 0
+    a, b = g.context(0).filter(2, 3, 0.5, 0.05), ctx.filter(2, 3, 0.5, 0.05)
+    assert np.allclose(a, b, rtol=1e-3, atol=1e-5)
+    with pytest.raises(NH.NoriHipError, match="listed twice"):
+        NH.Group([0, 0])
+    with pytest.raises(NH.NoriHipError):
+        NH.Group([NH.device_count()])
+    g.close(); hs.close()
+
+
+def test_devices_property_of_the_plugin_takes_the_group_path():
+    W, H, spp = 48, 40, 4
+    hs = NH.HostScene(XML, W, H, spp)
+    ctx = hs.preprocess(); ctx.render(0, spp)
+    want = ctx.read_film()
+    for part in ("spp", "tiles"):
+        os.environ.update(NORI_HIP_DEVICES="all", NORI_HIP_PARTITION=part)
+        try:
+            hg = NH.HostScene(XML, W, H, spp)
+            cg = hg.preprocess()
+        finally:
+            del os.environ["NORI_HIP_DEVICES"], os.environ["NORI_HIP_PARTITION"]
+        hg.render(0, 1); hg.render(1, spp)                        # Integrator::render through nori_hip_group_render
+        got = cg.read_film()
+        assert np.array_equal(got[..., 3], want[..., 3]) and np.allclose(got, want, rtol=1e-4, atol=1e-5)
+        hg.close()
+    hs.close()

@@ -80,3 +80,75 @@ def test_two_ranks_sum_to_the_single_process_film(tmp_path):
     # weights (sample counts) are integers and must match exactly; radiance sums differ by float addition order only
     assert np.array_equal(got[..., 3], want[..., 3])
     np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+
+
+# ---- the tile-list path and configs[4]'s reduce-then-filter on two gloo ranks --------------------------------------------
+W2, H2, SPP2 = 40, 72, 2            # three bands of 32 rows (the last one ragged): rank 0 gets two, rank 1 one
+FILTER = dict(r=2, f=3, sigma=0.5, h=0.05)
+
+
+def _to_srgb(v):
+    v = np.asarray(v, np.float32)
+    return np.where(v <= 0.0031308, 12.92 * v, 1.055 * np.power(np.maximum(v, 0), 1 / 2.4) - 0.055).astype(np.float32)   # src/common.cpp:192-206
+
+
+def _filter_film(O, film, border):
+    """what the filter pass does to a film: ImageBlock::toBitmap, sRGB, NL-means (cuda/filter.cc.cu:53-110)"""
+    inner = film[border:film.shape[0] - border, border:film.shape[1] - border]
+    w = inner[..., 3:4]
+    rgb = np.where(w != 0, inner[..., :3] / np.where(w != 0, w, 1), 0).astype(np.float32)
+    return O.nl_means(_to_srgb(rgb), FILTER["r"], FILTER["f"], FILTER["sigma"], FILTER["h"])
+
+
+def _tile_film(O, o, tiles, spp):
+    """the film of nori_hip_render_tiles(tiles, 0, spp) by the oracle: sample s of pixel (x, y) owns pcg32.seed(y W + x, s)"""
+    px, py, st, sq = [], [], [], []
+    for x0, y0, x1, y1 in tiles:
+        ys, xs = np.mgrid[y0:y1, x0:x1]
+        for s in range(spp):
+            px.append(xs.ravel()); py.append(ys.ravel()); st.append(ys.ravel() * W2 + xs.ravel()); sq.append(np.full(xs.size, s))
+    px, py, st, sq = (np.concatenate(a) for a in (px, py, st, sq))
+    rgb, ps = o.li_samples(px, py, st.astype(np.uint64), sq.astype(np.uint64))
+    return O.film_put(W2, H2, 2.0, ps, rgb)
+
+
+def _rank_tiles(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from nori_hip.partition import tile_bands, allreduce_film
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = O.OracleScene(os.path.join(ROOT, "scenes/cbox/cbox_path_mis.xml"), W2, H2, SPP2)
+    tiles = [(0, y0, W2, y1) for y0, y1 in tile_bands(rank, world, H2)]           # this rank's bands: ONE tile-list call on the GPU
+    film = torch.from_numpy(np.ascontiguousarray(_tile_film(O, o, tiles, SPP2)))
+    allreduce_film(film, dist)
+    dist.barrier()
+    if rank == 0:
+        # configs[4]: the filter pass runs once, after the reduce, on rank 0
+        np.save(out, film.numpy())
+        np.save(out + ".filtered.npy", _filter_film(O, film.numpy(), 2))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_tile_lists_then_filter_match_the_single_process_result(tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    out = str(tmp_path / "film_tiles.npy")
+    port = 31500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_tiles, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got, got_f = np.load(out), np.load(out + ".filtered.npy")
+    o = O.OracleScene(os.path.join(ROOT, "scenes/cbox/cbox_path_mis.xml"), W2, H2, SPP2)
+    o.render(0, SPP2, mode=1, threads=2)                     # the whole image in one process
+    want = o.film()
+    assert np.array_equal(got[..., 3], want[..., 3])
+    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got_f, _filter_film(O, want, 2), rtol=1e-3, atol=1e-5)
