@@ -110,6 +110,31 @@ __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const
     rgb[3 * i] = ps.li.x; rgb[3 * i + 1] = ps.li.y; rgb[3 * i + 2] = ps.li.z;
 }
 
+// BSDF::sample / eval / pdf alone (the BSDF mode of the reference's test plugins, src/ttest.cpp:107-147, src/chi2test.cpp:93-196)
+// out per query: weight rgb, wo xyz, pdf, eval rgb, isDelta, wo_valid
+__global__ __launch_bounds__(256) void k_bsdf_vectors(NoriHipShape b, size_t n, const float *wi, const float *sample, const float *sample2, const float *wo_in, float *out) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F3 w_i = f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    const F3 alb = f3(b.albedo);
+    F3 wo = f3(0.f), weight = f3(0.f); bool is_delta = false, wo_valid = true;
+    if (wo_in) wo = f3(wo_in[3 * i], wo_in[3 * i + 1], wo_in[3 * i + 2]);
+    else {
+        const F2 s1 = f2(sample[2 * i], sample[2 * i + 1]), s2 = sample2 ? f2(sample2[2 * i], sample2[2 * i + 1]) : s1;
+        weight = bsdf_sample(b, alb, w_i, s1, s2, wo, is_delta, wo_valid);
+    }
+    const float pdf = wo_valid ? bsdf_pdf(b, w_i, wo) : 0.f;
+    const F3 ev = wo_valid ? bsdf_eval(b, alb, w_i, wo) : f3(0.f);
+    float *o = out + 12 * i;
+    o[0] = weight.x; o[1] = weight.y; o[2] = weight.z; o[3] = wo.x; o[4] = wo.y; o[5] = wo.z; o[6] = pdf; o[7] = ev.x; o[8] = ev.y; o[9] = ev.z;
+    o[10] = is_delta ? 1.f : 0.f; o[11] = wo_valid ? 1.f : 0.f;
+}
+// n draws of pcg32.seed(state, seq) by one lane (known-answer test of the device sampler, ext/pcg32/pcg32-demo.out)
+__global__ void k_pcg32(uint64_t state, uint64_t seq, unsigned int n, uint32_t *out_u32, float *out_f32) {
+    Pcg32 r; r.seed(state, seq);
+    for (unsigned int i = 0; i < n; ++i) { if (out_u32) out_u32[i] = r.next_uint(); else out_f32[i] = r.next1D(); }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 struct RenderJob {
     int x0, y0, tw, th;               // the tile (n_tiles == 1)
@@ -1480,6 +1505,39 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
 }
 
 static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end);
+
+int nori_hip_bsdf_vectors(NoriHipContext *ctx, const NoriHipShape *bsdf, size_t n, const float *wi, const float *sample, const float *sample2, const float *wo, float *out) {
+    CTXCHK(ctx);
+    if (n == 0) return NORI_HIP_OK;
+    if (!bsdf || !wi || !out || (!sample && !wo)) return fail(NORI_HIP_EINVAL, "null buffer");
+    if (bsdf->bsdf < 0 || bsdf->bsdf > NORI_HIP_BSDF_SUBSURFACE) return fail(NORI_HIP_EINVAL, "unknown BSDF kind");
+    if (bsdf->albedo_tex || bsdf->normal_tex) return fail(NORI_HIP_EINVAL, "nori_hip_bsdf_vectors evaluates constant-colour BSDFs");
+    DevBufs bufs; float *d_wi = nullptr, *d_s = nullptr, *d_s2 = nullptr, *d_wo = nullptr, *d_out = nullptr;
+    HIPCHK(bufs.get(d_wi, n * 12)); HIPCHK(hipMemcpyAsync(d_wi, wi, n * 12, hipMemcpyHostToDevice, ctx->stream));
+    if (sample) { HIPCHK(bufs.get(d_s, n * 8)); HIPCHK(hipMemcpyAsync(d_s, sample, n * 8, hipMemcpyHostToDevice, ctx->stream)); }
+    if (sample2) { HIPCHK(bufs.get(d_s2, n * 8)); HIPCHK(hipMemcpyAsync(d_s2, sample2, n * 8, hipMemcpyHostToDevice, ctx->stream)); }
+    if (wo) { HIPCHK(bufs.get(d_wo, n * 12)); HIPCHK(hipMemcpyAsync(d_wo, wo, n * 12, hipMemcpyHostToDevice, ctx->stream)); }
+    HIPCHK(bufs.get(d_out, n * 48));
+    hipLaunchKernelGGL(k_bsdf_vectors, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, *bsdf, n, (const float *) d_wi, (const float *) d_s, (const float *) d_s2, (const float *) d_wo, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NORI_HIP_OK;
+}
+
+int nori_hip_pcg32(NoriHipContext *ctx, uint64_t state, uint64_t seq, size_t n, uint32_t *out_u32, float *out_f32) {
+    CTXCHK(ctx);
+    if (n == 0) return NORI_HIP_OK;
+    if ((out_u32 == nullptr) == (out_f32 == nullptr)) return fail(NORI_HIP_EINVAL, "exactly one of out_u32 / out_f32 must be given");
+    if (n > (1u << 20)) return fail(NORI_HIP_EINVAL, "nori_hip_pcg32 is a test entry: at most 2^20 draws");
+    DevBufs bufs; uint32_t *d = nullptr;
+    HIPCHK(bufs.get(d, n * 4));
+    hipLaunchKernelGGL(k_pcg32, dim3(1), dim3(1), 0, ctx->stream, state, seq, (unsigned int) n, out_u32 ? d : (uint32_t *) nullptr, out_u32 ? (float *) nullptr : (float *) d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_u32 ? (void *) out_u32 : (void *) out_f32, d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NORI_HIP_OK;
+}
 
 int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp_begin, int spp_end) {
     const int t[4] = {x0, y0, x1, y1};

@@ -6,7 +6,7 @@
 using namespace nori;
 
 struct NoriHostScene {
-    std::unique_ptr<NoriObject> root; std::vector<Scene *> scenes; StudentsTTest *test = nullptr;
+    std::unique_ptr<NoriObject> root; std::vector<Scene *> scenes; StudentsTTest *test = nullptr; ChiSquareTest *chi2 = nullptr;
     std::vector<std::unique_ptr<FlatScene>> flats;
     // programmatic scenes
     Scene *building = nullptr;
@@ -27,18 +27,19 @@ NoriHostScene *nori_host_load(const char *xml_path, int width, int height, int s
     try {
         std::string f(xml_path); size_t slash = f.find_last_of('/');
         getFileResolver()->prepend(slash == std::string::npos ? std::string(".") : f.substr(0, slash));
-        bool saved = StudentsTTest::s_runOnActivate; StudentsTTest::s_runOnActivate = false;
+        bool saved = StudentsTTest::s_runOnActivate, saved2 = ChiSquareTest::s_runOnActivate; StudentsTTest::s_runOnActivate = false; ChiSquareTest::s_runOnActivate = false;
         std::unique_ptr<NoriHostScene> h(new NoriHostScene());
-        try { h->root.reset(loadFromXML(f)); } catch (...) { StudentsTTest::s_runOnActivate = saved; throw; }
-        StudentsTTest::s_runOnActivate = saved;
+        try { h->root.reset(loadFromXML(f)); } catch (...) { StudentsTTest::s_runOnActivate = saved; ChiSquareTest::s_runOnActivate = saved2; throw; }
+        StudentsTTest::s_runOnActivate = saved; ChiSquareTest::s_runOnActivate = saved2;
         if (h->root->getClassType() == NoriObject::EScene) {
             Scene *s = static_cast<Scene *>(h->root.get()); h->scenes.push_back(s);
             if (width > 0 || height > 0) s->getCamera()->setOutputSize(width > 0 ? width : s->getCamera()->getWidth(), height > 0 ? height : s->getCamera()->getHeight());
             if (spp > 0) s->getSampler()->setSampleCount((size_t) spp);
         } else if (h->root->getClassType() == NoriObject::ETest) {
             h->test = dynamic_cast<StudentsTTest *>(h->root.get());
-            if (!h->test) throw NoriException("unsupported test type");
-            h->scenes = h->test->scenes();
+            h->chi2 = dynamic_cast<ChiSquareTest *>(h->root.get());
+            if (!h->test && !h->chi2) throw NoriException("unsupported test type");
+            if (h->test) h->scenes = h->test->scenes();
         } else throw NoriException("root element is neither a scene nor a test");
         h->flats.resize(h->scenes.size());
         return h.release();
@@ -164,6 +165,18 @@ int nori_host_test_run(NoriHostScene *h, int scene, double *out) {
         TTestResult r = h->test->runScene((size_t) scene);
         out[0] = r.mean; out[1] = r.variance; out[2] = r.reference; out[3] = r.t; out[4] = r.pvalue; out[5] = r.alpha; out[6] = r.passed ? 1.0 : 0.0;
         return 0;
+    )
+}
+int nori_host_bsdf_tests_run(NoriHostScene *h, double *out, int max_tests) {
+    GUARD(
+        if (!h || (!h->chi2 && !(h->test && h->test->bsdfMode()))) throw NoriException("not a BSDF test file (chi2test, or ttest with <bsdf> children)");
+        int n = 0;
+        if (h->chi2) {
+            for (const Chi2Result &r : h->chi2->run()) { if (n < max_tests) { double *o = out + 6 * n; o[0] = r.chsq; o[1] = r.dof; o[2] = r.pvalue; o[3] = r.alpha; o[4] = r.passed ? 1 : 0; o[5] = r.pooledCells; } ++n; }
+        } else {
+            for (const TTestResult &r : h->test->runBsdfs()) { if (n < max_tests) { double *o = out + 6 * n; o[0] = r.mean; o[1] = r.variance; o[2] = r.pvalue; o[3] = r.alpha; o[4] = r.passed ? 1 : 0; o[5] = r.reference; } ++n; }
+        }
+        return n;
     )
 }
 int nori_host_render_file(const char *xml_path, char *out_path, size_t out_len) {

@@ -201,10 +201,22 @@ TTestResult StudentsTTest::runScene(size_t i) {
     return studentsTTest(mean, variance, m_references.at(i), m_sampleCount, m_significanceLevel, (int) m_references.size());
 }
 void StudentsTTest::activate() {
-    if (!m_bsdfs.empty()) throw NoriException("StudentsTTest: BSDF-mode tests are not part of the path_mis hot path in this build");
-    if (m_references.size() != m_scenes.size()) throw NoriException("Specified a different number of scenes and reference values!");
+    if (!m_bsdfs.empty() && !s_runOnActivate) return;
+    if (m_bsdfs.empty() && m_references.size() != m_scenes.size()) throw NoriException("Specified a different number of scenes and reference values!");
     if (!s_runOnActivate) return;
     int passed = 0;
+    if (!m_bsdfs.empty()) {
+        m_results = runBsdfs();
+        for (const TTestResult &r : m_results) {
+            std::cout << "------------------------------------------------------\n"
+                      << "Sample mean = " << r.mean << " (reference value = " << r.reference << ")\nSample variance = " << r.variance
+                      << "\nt-statistic = " << r.t << " (d.o.f. = " << m_sampleCount - 1 << ")\n"
+                      << (r.passed ? "Accepted" : "***** Rejected *****") << " the null hypothesis (p-value = " << r.pvalue << ", significance level = " << r.alpha << ")" << std::endl;
+            if (r.passed) ++passed;
+        }
+        std::cout << "Passed " << passed << "/" << m_results.size() << " tests." << std::endl;
+        return;
+    }
     for (size_t i = 0; i < m_scenes.size(); ++i) {
         TTestResult r = runScene(i);
         m_results.push_back(r);

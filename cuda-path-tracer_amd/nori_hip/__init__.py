@@ -96,6 +96,8 @@ def hip_lib():
         L.nori_hip_reset_stats.argtypes = [vp]
         L.nori_hip_stream.argtypes = [vp, C.POINTER(vp)]
         L.nori_hip_synchronize.argtypes = [vp]
+        L.nori_hip_bsdf_vectors.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
+        L.nori_hip_pcg32.argtypes = [vp, C.c_uint64, C.c_uint64, sz, vp, vp]
         L.nori_hip_device_count.argtypes = [C.POINTER(i32)]
         L.nori_hip_group_create.argtypes = [vp, i32, C.POINTER(vp)]
         L.nori_hip_group_destroy.argtypes = [vp]
@@ -145,6 +147,7 @@ def host_lib():
         L.nori_host_render.argtypes = [vp, i32, i32, i32]
         L.nori_host_test_meta.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(i32)]
         L.nori_host_test_run.argtypes = [vp, i32, vp]
+        L.nori_host_bsdf_tests_run.argtypes = [vp, vp, i32]
         L.nori_host_render_file.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.nori_host_write_image.argtypes = [C.c_char_p, vp, i32, i32]
         _host = L
@@ -225,6 +228,25 @@ class Context:
         rgb = np.zeros((n, 3), np.float32)
         _hchk(self.L.nori_hip_li_samples(self.h, n, _vp(px), _vp(py), _vp(st), _vp(sq), _vp(rays), _vp(rgb)))
         return rgb
+
+    def bsdf_vectors(self, kind, params, wi, sample=None, wo=None, sample2=None):
+        """nori_hip_bsdf_vectors; params = albedo/kd rgb, alpha, intIOR, extIOR (the layout of tests/golden/bsdf.npz)"""
+        b = np.zeros(1, SHAPE_DTYPE)
+        p = np.asarray(params, np.float32)
+        b["bsdf"] = kind; b["albedo"] = p[0:3]; b["alpha"] = p[3]; b["int_ior"] = p[4]; b["ext_ior"] = p[5]; b["ks"] = np.float32(1.0) - p[0:3].max()
+        b["emitter"] = -1
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3)
+        sample = None if sample is None else np.ascontiguousarray(sample, np.float32).reshape(-1, 2)
+        sample2 = None if sample2 is None else np.ascontiguousarray(sample2, np.float32).reshape(-1, 2)
+        wo = None if wo is None else np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        out = np.zeros((len(wi), 12), np.float32)
+        _hchk(self.L.nori_hip_bsdf_vectors(self.h, _vp(b), len(wi), _vp(wi), _vp(sample), _vp(sample2), _vp(wo), _vp(out)))
+        return out
+
+    def pcg32(self, state, seq, n, floats=False):
+        out = np.zeros(n, np.float32 if floats else np.uint32)
+        _hchk(self.L.nori_hip_pcg32(self.h, state, seq, n, None if floats else _vp(out), _vp(out) if floats else None))
+        return out
 
     def render(self, spp_begin, spp_end, tile=None):
         if tile is None:
@@ -434,6 +456,13 @@ class HostScene:
         ref, n, sig, pm = C.c_float(), C.c_int(), C.c_float(), C.c_int()
         _ochk(self.L.nori_host_test_meta(self.h, scene, C.byref(ref), C.byref(n), C.byref(sig), C.byref(pm)))
         return dict(reference=ref.value, n=n.value, significance=sig.value, path_mis=bool(pm.value))
+
+    def bsdf_tests_run(self, max_tests=256):
+        """chi2test / BSDF-mode ttest files: one row of 6 values per test (include/nori_host.h)"""
+        out = np.zeros((max_tests, 6), np.float64)
+        n = self.L.nori_host_bsdf_tests_run(self.h, _vp(out), max_tests)
+        _ochk(n)
+        return out[:n]
 
     def test_run(self, scene):
         out = np.zeros(7, np.float64)

@@ -224,6 +224,19 @@ int nori_hip_camera_rays(NoriHipContext *ctx, const float *pixel_samples_xy, siz
 int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const int32_t *py, const uint64_t *states,
                         const uint64_t *seqs, const NoriHipRay *rays, float *rgb);
 
+/* The device's BSDF code alone, n queries of one constant-colour BSDF (bsdf->bsdf and its parameters; the shape fields of the
+ * record are ignored).  wo == NULL: BSDF::sample(bRec(wi[i]), sample[i], sample2[i]) (sample2 NULL: sample again; only the
+ * subsurface model reads it), then pdf and eval at the sampled direction.  wo != NULL: pdf and eval at (wi[i], wo[i]).
+ * out: 12 floats per query - weight rgb, wo xyz, pdf, eval rgb, isDelta, wo_valid (0: the reference's sample() returned early
+ * and left wo unset).  Replaces the direct BSDF calls of the reference's test plugins: the BSDF mode of the t-test
+ * (src/ttest.cpp:107-147) and the chi^2 test of sample() against pdf() (src/chi2test.cpp:93-196); the host plugins "ttest"
+ * and "chi2test" run on it.  No scene needs to be uploaded. */
+int nori_hip_bsdf_vectors(NoriHipContext *ctx, const NoriHipShape *bsdf, size_t n, const float *wi, const float *sample, const float *sample2,
+                          const float *wo, float *out);
+/* n draws of the device's pcg32 seeded (state, seq): raw 32-bit words (out_u32) or nextFloat() (out_f32), exactly one of the two.
+ * Known-answer test entry for ext/pcg32/pcg32-demo.out; Independent::next1D (src/independent.cpp:55-60). */
+int nori_hip_pcg32(NoriHipContext *ctx, uint64_t state, uint64_t seq, size_t n, uint32_t *out_u32, float *out_f32);
+
 /* Renders samples [spp_begin, spp_end) of every pixel of the tile [x0,x1) x [y0,y1) and ACCUMULATES them into
  * the film.  Sample s of pixel (x, y) uses the stream pcg32.seed(initstate = y*width + x, initseq = s).
  * Replaces the body of RenderThread::renderScene's pass loop: renderBlock + ImageBlock::put

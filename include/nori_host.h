@@ -51,6 +51,12 @@ int nori_host_render(NoriHostScene *h, int scene, int spp_begin, int spp_end);
 int nori_host_test_meta(NoriHostScene *h, int scene, float *reference, int *sample_count, float *significance, int *is_path_mis);
 int nori_host_test_run(NoriHostScene *h, int scene, double *out);
 
+/* The BSDF tests of a <test type="chi2test"> file, or of a <test type="ttest"> file with <bsdf> children (src/chi2test.cpp:93-196,
+ * src/ttest.cpp:107-147), run on the device's BSDF code.  Returns the number of tests (or -1); out receives 6 doubles per test, at
+ * most max_tests of them: chi2test - chi^2, d.o.f., p-value, alpha, passed, pooled cells; ttest - mean, variance, p-value, alpha,
+ * passed, reference.  Needs a GPU. */
+int nori_host_bsdf_tests_run(NoriHostScene *h, double *out, int max_tests);
+
 /* h x w x 3 linear rgb floats to a file: "*.exr" = OpenEXR, float R G B, uncompressed scanlines (Bitmap::save, src/bitmap.cpp:82-107),
  * "*.png" = 8-bit sRGB PNG (Bitmap::savePNG, :109-123), anything else = PFM */
 int nori_host_write_image(const char *path, const float *rgb, int w, int h);
