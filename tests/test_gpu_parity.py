@@ -88,6 +88,38 @@ def test_li_per_sample_against_reference_fixtures(name, loaded):
     err = np.abs(li - ref).max(1) / np.maximum(np.abs(ref).max(1), 1e-3)
     assert (err < 1e-3).mean() > 0.97, (err < 1e-3).mean()
     assert np.abs(li.mean(0) - ref.mean(0)).max() < 0.02 * ref.mean()
+    # The samples that do not match took another branch somewhere (a device-libm ulp at a roulette, lobe or emitter-pick
+    # comparison) and are from then on another, equally valid, random path.  What they add to or take from the mean is
+    # bounded: by their share of the samples times the spread of a sample, here with a factor of three.
+    bad = err >= 1e-3
+    if bad.any():
+        shift = np.abs((li[bad] - ref[bad]).sum(0)).max() / len(ref)
+        spread = max(float(ref.std(0).max()), float(ref.mean()))
+        assert shift < 3.0 * bad.mean() * spread + 1e-6, (name, shift, bad.mean(), spread)
+        # and they are not outliers: their own mean is that of ordinary samples, within their standard error (5 sigma)
+        se = ref.std(0).max() / np.sqrt(bad.sum())
+        assert np.abs(li[bad].mean(0) - ref.mean(0)).max() < 5.0 * se + 0.05 * ref.mean(), (name, li[bad].mean(0), ref.mean(0), se)
+
+
+def test_bench_scene_image_matches_oracle_at_matched_streams(loaded):
+    """table_path_mis_microfacet.xml (microfacet + dielectric, long glass paths: BASELINE configs[1]) at reduced resolution,
+    64 spp, per-sample streams identical on both sides: north_star's mean relative error <= 1e-3, per channel, and per pixel."""
+    W, H, spp = 80, 60, 64
+    hs, ctx = loaded("table_microfacet", W, H)
+    ctx.clear_film(); ctx.reset_stats()
+    ctx.render(0, spp)
+    img, film = ctx.read_bitmap(), ctx.read_film()
+    o = O.OracleScene(os.path.join(SCENES, SCENE_XML["table_microfacet"]), W, H, spp)
+    _, ost = o.render(0, spp, mode=1, threads=8)
+    oimg, ofilm = o.bitmap(), o.film()
+    assert np.array_equal(film[:, :, 3], ofilm[:, :, 3])
+    rel = np.abs(img.mean((0, 1)) - oimg.mean((0, 1))) / oimg.mean((0, 1))
+    assert rel.max() < 1e-3, rel
+    close = np.abs(img - oimg).max(2) <= 1e-3 + 1e-2 * oimg.max(2)
+    assert close.mean() > 0.95, close.mean()
+    st = ctx.stats()
+    assert st["camera_samples"] == W * H * spp
+    assert abs(st["closest_rays"] - ost["closest"]) < 2e-3 * ost["closest"] and abs(st["shadow_rays"] - ost["shadow"]) < 2e-3 * ost["shadow"]
 
 
 def test_li_on_reference_test_scenes_and_their_ttests(loaded):
