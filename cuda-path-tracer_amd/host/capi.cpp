@@ -167,6 +167,17 @@ int nori_host_test_run(NoriHostScene *h, int scene, double *out) {
         return 0;
     )
 }
+int nori_host_li(NoriHostScene *h, int scene, size_t n, const float *rays, float *rgb) {
+    GUARD(
+        Scene *s = sceneOf(h, scene);
+        for (size_t i = 0; i < n; ++i) {
+            const float *q = rays + 8 * i;
+            Color3f c = s->getIntegrator()->Li(s, s->getSampler(), Ray3f(Point3f(q[0], q[1], q[2]), Vector3f(q[4], q[5], q[6]), q[3], q[7]));
+            rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+        }
+        return 0;
+    )
+}
 int nori_host_bsdf_tests_run(NoriHostScene *h, double *out, int max_tests) {
     GUARD(
         if (!h || (!h->chi2 && !(h->test && h->test->bsdfMode()))) throw NoriException("not a BSDF test file (chi2test, or ttest with <bsdf> children)");

@@ -7,8 +7,14 @@
 #include <cstring>
 #include <iostream>
 #include <fstream>
+#include <atomic>
+#include <mutex>
 
 namespace nori {
+
+Color3f Integrator::Li(const Scene *, Sampler *, const Ray3f &) const {
+    throw NoriException::format("%s: Li() is not implemented by this integrator", toString().c_str());
+}
 
 static void hipCheck(int rc, const char *what) {
     if (rc != NORI_HIP_OK) throw NoriException::format("%s failed: %s", what, nori_hip_last_error());
@@ -99,6 +105,20 @@ public:
         need(); const NoriHipCamera &c = m_flat.desc.camera;
         rgb.resize((size_t) c.width * c.height * 3); hipCheck(nori_hip_read_bitmap(m_ctx, rgb.data()), "nori_hip_read_bitmap");
     }
+    /// Integrator::Li for one ray: PathMisIntegrator::Li (src/pathMisIntegrator.cpp:18-168) on the GPU through nori_hip_li_samples.
+    /// The reference draws from the caller's Sampler; here call k of this integrator owns the stream pcg32.seed(k, 0x4c69), which has
+    /// consumed the four draws of a camera sample (src/render.cpp:85-86) before the path starts.  preprocess() must have run.
+    Color3f Li(const Scene *, Sampler *, const Ray3f &ray) const override {
+        need();
+        const uint64_t state = m_liCalls.fetch_add(1), seq = 0x4c69;
+        NoriHipRay r; r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z; r.mint = ray.mint; r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z; r.maxt = ray.maxt;
+        float rgb[3] = {0, 0, 0};
+        {
+            std::lock_guard<std::mutex> lock(m_liMutex);                  // a context serves one caller at a time
+            hipCheck(nori_hip_li_samples(m_ctx, 1, nullptr, nullptr, &state, &seq, &r, rgb), "nori_hip_li_samples");
+        }
+        return Color3f(rgb[0], rgb[1], rgb[2]);
+    }
     NoriHipContext *context() override { return m_ctx; }
     NoriHipGroup *group() { return m_group; }
     const FlatScene &flat() const override { return m_flat; }
@@ -106,6 +126,7 @@ public:
 private:
     void need() const { if (!m_ctx) throw NoriException("path_mis: preprocess() has not run"); }
     int m_kind; int m_device = 0; bool m_deviceBvh = false, m_splat = false; NoriHipContext *m_ctx = nullptr; FlatScene m_flat;
+    mutable std::atomic<uint64_t> m_liCalls{0}; mutable std::mutex m_liMutex;
     bool m_allDevices = false; std::vector<int> m_devices; int m_partition = NORI_HIP_PARTITION_SPP; NoriHipGroup *m_group = nullptr;
 };
 static NoriObject *PathMisHip_create(const PropertyList &l) { return new PathMisHip(l); }

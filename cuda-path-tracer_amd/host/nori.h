@@ -37,6 +37,12 @@ public:
 struct Vector3f { float x = 0, y = 0, z = 0; Vector3f() {} Vector3f(float a, float b, float c) : x(a), y(b), z(c) {} explicit Vector3f(float a) : x(a), y(a), z(a) {}
     float operator[](int i) const { return (&x)[i]; } float &operator[](int i) { return (&x)[i]; } };
 typedef Vector3f Point3f; typedef Vector3f Normal3f; typedef Vector3f Color3f;
+/// include/nori/ray.h:38-100 (dRcp is recomputed on the device)
+struct Ray3f {
+    Point3f o; Vector3f d; float mint = 1e-4f, maxt = __builtin_huge_valf();
+    Ray3f() {}
+    Ray3f(const Point3f &o_, const Vector3f &d_, float mint_ = 1e-4f, float maxt_ = __builtin_huge_valf()) : o(o_), d(d_), mint(mint_), maxt(maxt_) {}
+};
 struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float a, float b) : x(a), y(b) {} };
 inline Vector3f operator+(Vector3f a, Vector3f b) { return Vector3f(a.x + b.x, a.y + b.y, a.z + b.z); }
 inline Vector3f operator-(Vector3f a, Vector3f b) { return Vector3f(a.x - b.x, a.y - b.y, a.z - b.z); }

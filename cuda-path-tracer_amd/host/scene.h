@@ -168,6 +168,9 @@ public:
     virtual void preprocess(const Scene *) {}
     /// true: the integrator builds the acceleration structure itself (on the device); Scene::activate then skips the host SAH build
     virtual bool buildsOwnBVH() const { return false; }
+    /// Radiance along one ray (include/nori/integrator.h:48-58).  The GPU integrators evaluate it as a batch of one - correct,
+    /// and as slow as one kernel launch per ray: render() / nori_hip_li_samples are the interfaces for throughput.
+    virtual Color3f Li(const Scene *scene, Sampler *sampler, const Ray3f &ray) const;
     /// Accumulates samples [spp_begin, spp_end) of every pixel into the integrator's film
     virtual void render(const Scene *scene, int spp_begin, int spp_end) = 0;
     /// rows x cols x 4 float film (ImageBlock layout) and its border

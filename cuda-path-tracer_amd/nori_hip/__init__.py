@@ -148,6 +148,7 @@ def host_lib():
         L.nori_host_test_meta.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(i32)]
         L.nori_host_test_run.argtypes = [vp, i32, vp]
         L.nori_host_bsdf_tests_run.argtypes = [vp, vp, i32]
+        L.nori_host_li.argtypes = [vp, i32, C.c_size_t, vp, vp]
         L.nori_host_render_file.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.nori_host_write_image.argtypes = [C.c_char_p, vp, i32, i32]
         _host = L
@@ -456,6 +457,13 @@ class HostScene:
         ref, n, sig, pm = C.c_float(), C.c_int(), C.c_float(), C.c_int()
         _ochk(self.L.nori_host_test_meta(self.h, scene, C.byref(ref), C.byref(n), C.byref(sig), C.byref(pm)))
         return dict(reference=ref.value, n=n.value, significance=sig.value, path_mis=bool(pm.value))
+
+    def li(self, rays, scene=0):
+        """Integrator::Li, one virtual call per ray (the reference's per-ray interface)"""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        rgb = np.zeros((len(rays), 3), np.float32)
+        _ochk(self.L.nori_host_li(self.h, scene, len(rays), _vp(rays), _vp(rgb)))
+        return rgb
 
     def bsdf_tests_run(self, max_tests=256):
         """chi2test / BSDF-mode ttest files: one row of 6 values per test (include/nori_host.h)"""

@@ -51,6 +51,10 @@ int nori_host_render(NoriHostScene *h, int scene, int spp_begin, int spp_end);
 int nori_host_test_meta(NoriHostScene *h, int scene, float *reference, int *sample_count, float *significance, int *is_path_mis);
 int nori_host_test_run(NoriHostScene *h, int scene, double *out);
 
+/* Integrator::Li (include/nori/integrator.h:48-58) of the scene's integrator for n rays (8 floats each: o, mint, d, maxt), one
+ * virtual call per ray as a Nori-side caller would make it; 3 floats per ray out.  preprocess must have run. */
+int nori_host_li(NoriHostScene *h, int scene, size_t n, const float *rays, float *rgb);
+
 /* The BSDF tests of a <test type="chi2test"> file, or of a <test type="ttest"> file with <bsdf> children (src/chi2test.cpp:93-196,
  * src/ttest.cpp:107-147), run on the device's BSDF code.  Returns the number of tests (or -1); out receives 6 doubles per test, at
  * most max_tests of them: chi2test - chi^2, d.o.f., p-value, alpha, passed, pooled cells; ttest - mean, variance, p-value, alpha,

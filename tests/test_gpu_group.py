@@ -56,3 +56,16 @@ def test_devices_property_of_the_plugin_takes_the_group_path():
         assert np.array_equal(got[..., 3], want[..., 3]) and np.allclose(got, want, rtol=1e-4, atol=1e-5)
         hg.close()
     hs.close()
+
+
+def test_per_ray_li_of_the_plugin_is_the_batched_li():
+    """Integrator::Li(scene, sampler, ray), the reference's per-ray interface (include/nori/integrator.h:48-58), on the GPU plugin:
+    call k owns the stream pcg32.seed(k, 0x4c69), so it equals nori_hip_li_samples on the same rays and streams"""
+    hs = NH.HostScene(XML, 32, 32, 1)
+    ctx = hs.preprocess()
+    rng = np.random.default_rng(2)
+    rays = ctx.camera_rays((rng.random((200, 2)) * 32).astype(np.float32))
+    a = hs.li(rays)
+    b = ctx.li_samples(np.arange(200, dtype=np.uint64), np.full(200, 0x4c69, np.uint64), rays=rays)
+    assert np.array_equal(a, b) and a.sum() > 0
+    hs.close()
