@@ -834,18 +834,23 @@ __device__ __forceinline__ bool trace_masked(const DevScene &sc, const Ray &ray,
 
 struct Counters { uint32_t closest, shadow, nodes, prims; };
 
-// The part of one bounce between the closest-hit query and the shadow query (src/pathMisIntegrator.cpp:42-164):
-// emission with the MIS weight of the previous BSDF sample, Russian roulette, BSDF sampling, emitter sampling.
-// Updates ps (radiance so far, throughput, next ray, last pdf); out.contrib is what the NEE adds if the shadow ray
-// is unoccluded.  out.end: the path stops after this bounce (roulette, or a zero BSDF weight — the reference keeps
-// bouncing with zero throughput, which adds exact zeros).
-// EXT: scenes with images (albedo textures, bump / normal maps) or subsurface shapes; the probe rays of the latter
-// are traced here, by the shading lane (`ctr`, if given, counts them as closest-hit rays).
+// shade_hit in pieces, so that the wavefront pipeline can put a trace stage between drawing a subsurface probe and using its hit:
+//   shade_ctx     what every piece needs about the hit: surface record, local incident direction, albedo at the hit's uv
+//   shade_begin   emission + MIS weight of the previous BSDF sample, Russian roulette (:42-77); false: the path ends here
+//   ss_probe_ray  Subsurface::sampleDx (src/subsurface.cpp:199-249): one probe ray; consumes next1D + next2D
+//   shade_finish  BSDF sample, emitter sample, next ray (:103-164), continuing from (op, osh) = its_out
+struct ShadeCtx { Surface sf; F3 wi_l, alb; };
 template <bool EXT = false>
-__device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg32 &rng, const Hit &hit, ShadeOut &out, Counters *ctr = nullptr) {
+__device__ __forceinline__ void shade_ctx(const DevScene &sc, const Ray &ray, const Hit &hit, ShadeCtx &cx) {
+    surface_from_hit<EXT>(sc, ray, hit, cx.sf, false);
+    const NoriHipShape &shp = sc.shapes[cx.sf.shape];
+    cx.wi_l = cx.sf.sh.toLocal(-ray.d);                                   // :81-87
+    cx.alb = f3(shp.albedo);
+    if (EXT && shp.albedo_tex) cx.alb = tex_color(sc, sc.textures[shp.albedo_tex - 1], cx.sf.uv);
+}
+__device__ __forceinline__ bool shade_begin(const DevScene &sc, PathState &ps, Pcg32 &rng, const ShadeCtx &cx, ShadeOut &out) {
     out.end = false; out.has_shadow = false; out.contrib = f3(0.f);
-    Surface sf;
-    surface_from_hit<EXT>(sc, ps.ray, hit, sf, false);
+    const Surface &sf = cx.sf;
     const NoriHipShape &shp = sc.shapes[sf.shape];
     if (shp.emitter >= 0) {                                               // :42-63
         const NoriHipEmitter &em = sc.emitters[shp.emitter];
@@ -857,30 +862,22 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
         if (wmat > 0.0f) ps.li = ps.li + (wmat * ps.t) * flight;
     }
     const float successProb = 0.95f;                                      // :67-77
-    if (rng.next1D() > successProb) { out.end = true; return; }
+    if (rng.next1D() > successProb) { out.end = true; return false; }
     ps.t = ps.t / successProb;
-
-    F3 wi_l = sf.sh.toLocal(-ps.ray.d);                                   // :81-109
-    F3 alb = f3(shp.albedo);
-    if (EXT && shp.albedo_tex) alb = tex_color(sc, sc.textures[shp.albedo_tex - 1], sf.uv);
-    // its_out: where the path continues from.  The hit itself, except for subsurface shapes (:86-100)
-    F3 op = sf.p; Frame osh = sf.sh;
-    if (EXT && shp.bsdf == NORI_HIP_BSDF_SUBSURFACE) {
-        bool found = false;
-        for (int tries = 0; tries < ND_PROBE_TRIES && !found; ++tries) {  // Subsurface::sampleDx, src/subsurface.cpp:199-249
-            float thres = rng.next1D();
-            F3 d = thres < 0.5f ? -sf.sh.n : thres < 0.625f ? sf.sh.t : thres < 0.75f ? -sf.sh.t : thres < 0.875f ? sf.sh.s : -sf.sh.s;
-            F2 dx = ss_sample_disk(rng.next2D(), shp.ss_cs, shp.ss_cd);
-            Frame fr; fr.set(-d);
-            Ray probe; probe.d = d; probe.o = sf.p + fr.toWorld(f3(dx.x, dx.y, 0.f));
-            probe.mint = -1e-3f; probe.maxt = nd_sqrt(dx.x * dx.x + dx.y * dx.y) + 1e-3f;
-            Hit ph; uint32_t nn = 0, np = 0;
-            found = trace_masked(sc, probe, sf.shape, ph, nn, np);
-            if (ctr) { ctr->closest++; ctr->nodes += nn; ctr->prims += np; }
-            if (found) { Surface so; surface_from_hit<EXT>(sc, probe, ph, so, false); op = so.p; osh = so.sh; }
-        }
-        if (!found) { out.end = true; return; }
-    }
+    return true;
+}
+__device__ __forceinline__ void ss_probe_ray(const DevScene &sc, const ShadeCtx &cx, Pcg32 &rng, Ray &probe) {
+    const Surface &sf = cx.sf; const NoriHipShape &shp = sc.shapes[sf.shape];
+    float thres = rng.next1D();
+    F3 d = thres < 0.5f ? -sf.sh.n : thres < 0.625f ? sf.sh.t : thres < 0.75f ? -sf.sh.t : thres < 0.875f ? sf.sh.s : -sf.sh.s;
+    F2 dx = ss_sample_disk(rng.next2D(), shp.ss_cs, shp.ss_cd);
+    Frame fr; fr.set(-d);
+    probe.d = d; probe.o = sf.p + fr.toWorld(f3(dx.x, dx.y, 0.f));
+    probe.mint = -1e-3f; probe.maxt = nd_sqrt(dx.x * dx.x + dx.y * dx.y) + 1e-3f;
+}
+__device__ __forceinline__ void shade_finish(const DevScene &sc, PathState &ps, Pcg32 &rng, const ShadeCtx &cx, F3 op, const Frame &osh, ShadeOut &out) {
+    const NoriHipShape &shp = sc.shapes[cx.sf.shape];
+    const F3 wi_l = cx.wi_l, alb = cx.alb;
     F2 s2 = rng.next2D(); F2 s1 = rng.next2D();                           // second argument is drawn first
     F3 wo; bool is_delta, wo_valid;
     F3 f = bsdf_sample(shp, alb, wi_l, s1, s2, wo, is_delta, wo_valid);
@@ -906,6 +903,33 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
     if (!wo_valid || is_zero(f)) { out.end = true; return; }
     ps.ray.d = next_dir; ps.ray.o = op; ps.ray.mint = 1e-3f; ps.ray.maxt = ND_INF;
     ps.t = ps.t * f;
+}
+
+// The part of one bounce between the closest-hit query and the shadow query (src/pathMisIntegrator.cpp:42-164):
+// emission with the MIS weight of the previous BSDF sample, Russian roulette, BSDF sampling, emitter sampling.
+// Updates ps (radiance so far, throughput, next ray, last pdf); out.contrib is what the NEE adds if the shadow ray
+// is unoccluded.  out.end: the path stops after this bounce (roulette, or a zero BSDF weight — the reference keeps
+// bouncing with zero throughput, which adds exact zeros).
+// EXT: scenes with images (albedo textures, bump / normal maps) or subsurface shapes; the probe rays of the latter
+// are traced here, by the shading lane (`ctr`, if given, counts them as closest-hit rays).
+template <bool EXT = false>
+__device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg32 &rng, const Hit &hit, ShadeOut &out, Counters *ctr = nullptr) {
+    ShadeCtx cx; shade_ctx<EXT>(sc, ps.ray, hit, cx);
+    if (!shade_begin(sc, ps, rng, cx, out)) return;
+    // its_out: where the path continues from.  The hit itself, except for subsurface shapes (:86-100)
+    F3 op = cx.sf.p; Frame osh = cx.sf.sh;
+    if (EXT && sc.shapes[cx.sf.shape].bsdf == NORI_HIP_BSDF_SUBSURFACE) {
+        bool found = false;
+        for (int tries = 0; tries < ND_PROBE_TRIES && !found; ++tries) {
+            Ray probe; ss_probe_ray(sc, cx, rng, probe);
+            Hit ph; uint32_t nn = 0, np = 0;
+            found = trace_masked(sc, probe, cx.sf.shape, ph, nn, np);
+            if (ctr) { ctr->closest++; ctr->nodes += nn; ctr->prims += np; }
+            if (found) { Surface so; surface_from_hit<EXT>(sc, probe, ph, so, false); op = so.p; osh = so.sh; }
+        }
+        if (!found) { out.end = true; return; }
+    }
+    shade_finish(sc, ps, rng, cx, op, osh, out);
 }
 
 // One iteration of the reference's bounce loop, run to completion by one lane.  Returns false when the path ended.
