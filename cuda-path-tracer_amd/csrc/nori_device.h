@@ -341,6 +341,15 @@ template <bool ANY> struct Trav {
         float4 A, B, C; prim_fetch(sc, A, B, C);
         prim_compute(A, B, C, n_prims, any);
     }
+    // the same for a query restricted to the records of shape `mask` (BVH::rayIntersect's mask argument, src/bvh.cpp:438;
+    // 0xffffffff: no restriction): a record of another shape is stepped over.  Returns whether the record was tested.
+    __device__ __forceinline__ bool prim_step_masked(const DevScene &sc, uint32_t &n_prims, const bool any, const uint32_t mask) {
+        float4 A, B, C; prim_fetch(sc, A, B, C);
+        const uint32_t fl = __float_as_uint(C.z);
+        if (mask == 0xffffffffu || (fl & 0xffffffu) == mask) { prim_compute(A, B, C, n_prims, any); return true; }
+        cur = (fl & 0x80000000u) ? ND_POP : (NORI_HIP_LEAF_BIT | ((cur & 0x7fffffffu) + 1u));
+        return false;
+    }
     __device__ __forceinline__ void prim_fetch(const DevScene &sc, float4 &A, float4 &B, float4 &C) const {
         const float4 *r = sc.prims + 3 * (size_t) (cur & 0x7fffffffu);
         A = r[0]; B = r[1]; C = r[2];
@@ -930,6 +939,26 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
         if (!found) { out.end = true; return; }
     }
     shade_finish(sc, ps, rng, cx, op, osh, out);
+}
+
+// A bounce that the wavefront pipeline left between its two halves: the hit `hit0` of ray `ray0` was shaded up to the roulette and
+// the probe `probe` (attempt number `tries`, 0-based) was traced with result `ph` (pos = 0xffffffff: it missed).  Finishes the
+// bounce in one go, with further probes traced by this lane if that one missed (the tail kernel's way).
+template <bool EXT = true>
+__device__ __forceinline__ void shade_resume(const DevScene &sc, PathState &ps, Pcg32 &rng, const Ray &ray0, const Hit &hit0, Ray probe, Hit ph, int tries,
+                                             ShadeOut &out, Counters *ctr) {
+    out.end = false; out.has_shadow = false; out.contrib = f3(0.f);
+    ShadeCtx cx; shade_ctx<EXT>(sc, ray0, hit0, cx);
+    bool found = ph.pos != 0xffffffffu;
+    for (++tries; tries < ND_PROBE_TRIES && !found; ++tries) {
+        ss_probe_ray(sc, cx, rng, probe);
+        uint32_t nn = 0, np = 0;
+        found = trace_masked(sc, probe, cx.sf.shape, ph, nn, np);
+        if (ctr) { ctr->closest++; ctr->nodes += nn; ctr->prims += np; }
+    }
+    if (!found) { out.end = true; return; }
+    Surface so; surface_from_hit<EXT>(sc, probe, ph, so, false);
+    shade_finish(sc, ps, rng, cx, so.p, so.sh, out);
 }
 
 // One iteration of the reference's bounce loop, run to completion by one lane.  Returns false when the path ended.

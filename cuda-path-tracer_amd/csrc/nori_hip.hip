@@ -306,7 +306,10 @@ __global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 //   k_trace_pool<!ANY>    extend stage: closest hit for the next rays, writes the hit record per slot
 // All three walk the pool in slot order, so their HBM accesses are coalesced, and nothing but the work counter,
 // the live count and the statistics is shared between waves.
-enum { PF_LAST_DELTA = 1u, PF_ENDING = 2u, PF_ACTIVE = 4u, PF_SHADOW = 8u };
+enum { PF_LAST_DELTA = 1u, PF_ENDING = 2u, PF_ACTIVE = 4u, PF_SHADOW = 8u,
+       PF_PROBE = 16u,                  // the slot's ray is a subsurface probe: its hit ends the bounce that sv_o / sv_d / sv_h began
+       PF_TRIES_SHIFT = 8 };            // bits 8..20: probes of this bounce that missed so far
+#define ND_PROBE_MARK 0xfffffffeu       /* hit.x of a slot whose ray is a probe (hit.y = the shape it is restricted to), read by the trace stage */
 
 struct Pool {
     float4 *ray_o;     // o.xyz, mint
@@ -319,7 +322,9 @@ struct Pool {
     float4 *sh_o;      // shadow ray o.xyz, mint
     float4 *sh_d;      // shadow ray d.xyz, maxt     (maxt < mint: no ray)
     float4 *sh_c;      // NEE contribution rgb if unoccluded; w: set to 1 by the shadow stage when unoccluded
+    float4 *sv_o, *sv_d; uint4 *sv_h;   // PF_PROBE: the ray and hit record of the bounce the probe belongs to
 };
+#define ND_POOL_ARRAYS 13
 
 // Counters, one per 256-byte line (see DevStats).  v[0]: slots that hold a live path after the last shade stage.
 #define ND_LINE 64                              /* unsigned ints per 256-byte line */
@@ -349,6 +354,7 @@ __global__ __launch_bounds__(256) void k_compact_pool(Pool src, Pool dst, const 
         const unsigned int s = q_live[i];
         dst.ray_o[i] = src.ray_o[s]; dst.ray_d[i] = src.ray_d[s]; dst.hit[i] = src.hit[s]; dst.thr[i] = src.thr[s]; dst.li[i] = src.li[s];
         dst.rng[i] = src.rng[s]; dst.pix[i] = src.pix[s]; dst.sh_o[i] = src.sh_o[s]; dst.sh_d[i] = src.sh_d[s]; dst.sh_c[i] = src.sh_c[s];
+        if (__float_as_uint(dst.li[i].w) & PF_PROBE) { dst.sv_o[i] = src.sv_o[s]; dst.sv_d[i] = src.sv_d[s]; dst.sv_h[i] = src.sv_h[s]; }
     } else {
         dst.li[i] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
         dst.ray_d[i] = make_float4(0.f, 0.f, 0.f, -1.f); dst.ray_o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -413,7 +419,6 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
     const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
     unsigned int n_invalid = 0, n_degenerate = 0;
-    Counters probe_ctr = {0, 0, 0, 0};                                      // EXT: probe rays traced while shading
     const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
     if (threadIdx.x == 0) { l_regen = 0u; l_keep = 0u; }
     __syncthreads();
@@ -430,13 +435,56 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                 PathState ps; ps.li = add_pending_nee(f3(L.x, L.y, L.z), flags, C);
                 bool ended = true, new_shadow = false;
                 idle = false;
-                if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
+                ShadeOut so; bool shaded = false;
+                Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
+                ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
+                if (EXT && (flags & PF_PROBE)) {
+                    // second half of a bounce on a subsurface shape: the probe drawn in the first half has been traced
+                    const float4 so4 = pool.sv_o[slot], sd4 = pool.sv_d[slot]; const uint4 sh4 = pool.sv_h[slot];
+                    Ray ray0; ray0.o = f3(so4.x, so4.y, so4.z); ray0.mint = so4.w; ray0.d = f3(sd4.x, sd4.y, sd4.z); ray0.maxt = sd4.w;
+                    Hit hit0; hit0.pos = sh4.x; hit0.t = __uint_as_float(sh4.y); hit0.u = __uint_as_float(sh4.z); hit0.v = __uint_as_float(sh4.w);
+                    ShadeCtx cx; shade_ctx<EXT>(sc, ray0, hit0, cx);
+                    ps.ray = ray0;
+                    if (h.x != 0xffffffffu) {
+                        Ray probe; probe.o = f3(ro.x, ro.y, ro.z); probe.mint = ro.w; probe.d = f3(rd.x, rd.y, rd.z); probe.maxt = rd.w;
+                        Hit ph; ph.pos = h.x; ph.t = __uint_as_float(h.y); ph.u = __uint_as_float(h.z); ph.v = __uint_as_float(h.w);
+                        Surface sp; surface_from_hit<EXT>(sc, probe, ph, sp, false);
+                        so.end = false; so.has_shadow = false; so.contrib = f3(0.f);
+                        shade_finish(sc, ps, rng, cx, sp.p, sp.sh, so);
+                        shaded = true;
+                    } else {
+                        // the probe left the shape: the reference draws another one (src/pathMisIntegrator.cpp:88-90), up to ND_PROBE_TRIES here
+                        const unsigned int tries = ((flags >> PF_TRIES_SHIFT) & 0x1fffu) + 1u;
+                        if (tries < ND_PROBE_TRIES) {
+                            Ray probe; ss_probe_ray(sc, cx, rng, probe);
+                            pool.ray_o[slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, probe.mint);
+                            pool.ray_d[slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, probe.maxt);
+                            pool.hit[slot] = make_uint4(ND_PROBE_MARK, cx.sf.shape, 0u, 0u);
+                            pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
+                            pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float((flags & (PF_ACTIVE | PF_LAST_DELTA | PF_PROBE)) | (tries << PF_TRIES_SHIFT)));
+                            ended = false;
+                        }
+                    }
+                } else if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
                     ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
-                    ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
-                    Pcg32 rng; rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
                     Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
-                    ShadeOut so;
-                    shade_hit<EXT>(sc, ps, rng, hit, so, EXT ? &probe_ctr : nullptr);
+                    ShadeCtx cx; shade_ctx<EXT>(sc, ps.ray, hit, cx);
+                    if (!shade_begin(sc, ps, rng, cx, so)) shaded = true;                       // roulette: so.end is set
+                    else if (EXT && sc.shapes[cx.sf.shape].bsdf == NORI_HIP_BSDF_SUBSURFACE) {
+                        // first half of a bounce on a subsurface shape (src/pathMisIntegrator.cpp:86-100): the probe goes through the
+                        // trace stage like any other ray, restricted to this shape; the bounce is finished when its hit is back
+                        Ray probe; ss_probe_ray(sc, cx, rng, probe);
+                        pool.sv_o[slot] = ro; pool.sv_d[slot] = rd; pool.sv_h[slot] = h;
+                        pool.ray_o[slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, probe.mint);
+                        pool.ray_d[slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, probe.maxt);
+                        pool.hit[slot] = make_uint4(ND_PROBE_MARK, cx.sf.shape, 0u, 0u);
+                        pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
+                        pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
+                        pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(PF_ACTIVE | PF_PROBE | (flags & PF_LAST_DELTA)));
+                        ended = false;
+                    } else { shade_finish(sc, ps, rng, cx, cx.sf.p, cx.sf.sh, so); shaded = true; }
+                }
+                if (shaded) {
                     flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
                     if (so.has_shadow) {
                         flags |= PF_SHADOW;
@@ -526,11 +574,6 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     unsigned long long v0 = n_samples, v1 = n_invalid, v2 = n_degenerate;
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); v2 += __shfl_down(v2, off, 64); }
     if (lane == 0 && (v0 | v1 | v2)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); if (v2) atomicAdd(&st->shadow, v2); }
-    if (EXT) {
-        unsigned long long w[3] = {probe_ctr.closest, probe_ctr.nodes, probe_ctr.prims};
-        for (int k = 0; k < 3; ++k) for (int off = 32; off > 0; off >>= 1) w[k] += __shfl_down(w[k], off, 64);
-        if (lane == 0 && w[0]) { DevStats *st = my_stats(stats); atomicAdd(&st->closest, w[0]); atomicAdd(&st->nodes, w[1]); atomicAdd(&st->prims, w[2]); }
-    }
 }
 // built for several register budgets (waves per SIMD); the stage is bound by the latency of its dependent fetches
 #define ND_SHADE_KERNEL(W) \
@@ -583,7 +626,9 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 #ifndef ND_WIDE_WAVES
 #define ND_WIDE_WAVES 5         /* waves per SIMD the four-box trace stage is built for */
 #endif
-template <int KIND, bool PROF, bool SPEC, bool WIDE>
+// MASKED (scenes with subsurface shapes): an extend ray whose slot holds ND_PROBE_MARK is a probe, a closest-hit query restricted
+// to the records of one shape (BVH::rayIntersect's mask, src/bvh.cpp:438).
+template <int KIND, bool PROF, bool SPEC, bool WIDE, bool MASKED = false>
 __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
     constexpr int DEPTH = WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
@@ -621,6 +666,7 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
     bool l_any = ANY;                                                    // wave-uniform: kind of the batch in flight
     Trav<ANY> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
     bool have = false; unsigned int slot = 0;
+    uint32_t mask = 0xffffffffu;                                         // MASKED: the shape this lane's ray is restricted to
     uint32_t pend = 0u;                                                  // SPEC: the parked leaf's next record (NORI_HIP_LEAF_BIT | position), 0 = none
     // statistics are wave-uniform sums of ballots (scalar registers): records and boxes tested, rays by kind
     unsigned int n_boxes = 0, n_prims = 0, n_rays = 0, n_rays_any = 0;
@@ -698,6 +744,7 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
                     const float4 ro = st_o[idx], rd = st_d[idx], rr = st_r[idx]; slot = st_slot[idx];
                     if (KIND == TK_BOTH) any = (slot >> 31) != 0u;
                     tv.special = (slot & 0x40000000u) != 0u; slot &= 0x3fffffffu;
+                    if (MASKED) { mask = 0xffffffffu; if (!((KIND == TK_BOTH) ? any : ANY)) { const uint4 hin = pool.hit[slot]; if (hin.x == ND_PROBE_MARK) mask = hin.y; } }
                     tv.o = f3(ro.x, ro.y, ro.z); tv.mint = ro.w; tv.d = f3(rd.x, rd.y, rd.z); tv.maxt = rd.w; tv.rcp = f3(rr.x, rr.y, rr.z);
                     tv.sp = 0; tv.found = false; tv.cur = WIDE ? sc.root4 : sc.root; tv.cur_near = -ND_INF;       // (the root box was tested at staging; the root may be a leaf)
                     tv.hit.pos = 0xffffffffu; tv.hit.t = ND_INF; tv.hit.u = tv.hit.v = 0.f;
@@ -729,8 +776,14 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
             const unsigned long long m_lf = __ballot(tv.at_leaf());
             if (m_lf && (__popcll(m_lf) >= thr.y || !ran)) {
                 if (PROF) { pf[3]++; pf[4] += __popcll(m_lf); }
-                n_prims += (unsigned int) __popcll(m_lf);
-                if (tv.at_leaf()) tv.prim_step(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
+                if (MASKED) {
+                    bool tested = false;
+                    if (tv.at_leaf()) tested = tv.prim_step_masked(sc, dummy, (KIND == TK_BOTH) ? any : ANY, mask);
+                    n_prims += (unsigned int) __popcll(__ballot(tested));
+                } else {
+                    n_prims += (unsigned int) __popcll(m_lf);
+                    if (tv.at_leaf()) tv.prim_step(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
+                }
             }
         }
         if (PROF) { const unsigned long long m_pp = __ballot(tv.at_pop()); if (m_pp) { pf[5]++; pf[6] += __popcll(m_pp); } }
@@ -785,6 +838,10 @@ template <int KIND, bool PROF, bool SPEC = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
     trace_pool_body<KIND, PROF, SPEC, false>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, nullptr);
 }
+// ... for scenes with subsurface shapes (probe rays; no speculative traversal)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4_masked(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
+    trace_pool_body<TK_BOTH, false, false, true, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
+}
 // the merged trace stage over four-box nodes
 template <bool PROF, bool SPEC>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
@@ -808,6 +865,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
     bool alive = false; unsigned int slot = 0;
     PathState ps; Pcg32 rng; Hit hit; float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+    // EXT: a slot taken over between the two halves of a subsurface bounce (PF_PROBE): its first trip finishes that bounce
+    bool resume = false; Ray probe0; Hit hit0; int tries0 = 0;
+    probe0.o = probe0.d = f3(0.f); probe0.mint = probe0.maxt = 0.f; hit0.pos = 0u; hit0.t = hit0.u = hit0.v = 0.f;
     if (batch >= n_batches) return;
     for (;;) {
         const unsigned long long dead = __ballot(!alive);
@@ -821,13 +881,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const uint4 h = pool.hit[slot];
                     P = pool.pix[slot];
                     ps.li = add_pending_nee(f3(L.x, L.y, L.z), flags, pool.sh_c[slot]);
-                    if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
+                    if (EXT && (flags & PF_PROBE)) {
+                        const float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; const uint4 R = pool.rng[slot];
+                        const float4 so4 = pool.sv_o[slot], sd4 = pool.sv_d[slot]; const uint4 sh4 = pool.sv_h[slot];
+                        probe0.o = f3(ro.x, ro.y, ro.z); probe0.mint = ro.w; probe0.d = f3(rd.x, rd.y, rd.z); probe0.maxt = rd.w;
+                        ps.ray.o = f3(so4.x, so4.y, so4.z); ps.ray.mint = so4.w; ps.ray.d = f3(sd4.x, sd4.y, sd4.z); ps.ray.maxt = sd4.w;
+                        hit0.pos = sh4.x; hit0.t = __uint_as_float(sh4.y); hit0.u = __uint_as_float(sh4.z); hit0.v = __uint_as_float(sh4.w);
+                        ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
+                        rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
+                        hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);       // the probe's hit
+                        tries0 = (int) ((flags >> PF_TRIES_SHIFT) & 0x1fffu);
+                        resume = true; alive = true;
+                    } else if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
                         const float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; const uint4 R = pool.rng[slot];
                         ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
                         ps.t = f3(T.x, T.y, T.z); ps.last_bsdf_pdf = T.w; ps.last_delta = (flags & PF_LAST_DELTA) != 0;
                         rng.state = ((uint64_t) R.y << 32) | R.x; rng.inc = ((uint64_t) R.w << 32) | R.z;
                         hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
-                        alive = true;
+                        resume = false; alive = true;
                     } else {
                         const unsigned int pxy = __float_as_uint(P.z);
                         if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
@@ -843,7 +914,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (alive) {
             // one bounce: the hit is in registers
             ShadeOut so;
-            shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
+            if (EXT && resume) { const Ray ray0 = ps.ray; shade_resume<EXT>(sc, ps, rng, ray0, hit0, probe0, hit, tries0, so, &ctr); resume = false; }
+            else shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
             if (so.has_shadow) {
                 Hit sh; ctr.shadow++;
                 if (!(WIDE ? trace4<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims))) ps.li = ps.li + so.contrib;
@@ -1038,6 +1110,7 @@ struct NoriHipContext {
     NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
     float *d_filt = nullptr; float filt_radius = 0.f;   // nori_hip_set_film_filter (kept across scene uploads)
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
+    bool has_ss = false;              // ... subsurface shapes: the wavefront pipeline traces their probe rays in its trace stage
     int integrator = NORI_HIP_INTEGRATOR_PATH_MIS;   // nori_hip_set_integrator
     lbvh::Result lbvh;                // what nori_hip_upload_scene_build built (zeros after nori_hip_upload_scene)
     uint32_t lbvh_leaf = 0;           // records per leaf of a device-built tree (NORI_HIP_LBVH_LEAF); 0 = 3, or 2 from a million records on (measured)
@@ -1189,6 +1262,7 @@ static int create_impl(NoriHipContext *c, int device) {
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_SHADOW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
     c->trace_lds_wide = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH_W * 64 * 8 + 64 * 52);
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4_masked, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
@@ -1378,7 +1452,9 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     if ((rc = upload(ctx->d_cdf, d->cdf, d->n_cdf))) return rc;
     if ((rc = upload(ctx->d_textures, d->textures, d->n_textures))) return rc;
     if ((rc = upload(ctx->d_tex_data, d->tex_data, d->n_textures ? (size_t) d->n_tex_bytes : 0))) return rc;
-    ctx->ext = ext; ctx->n_prims = d->n_prims; ctx->n_nodes = device_build ? ctx->lbvh.n_nodes : d->n_nodes;
+    ctx->ext = ext; ctx->has_ss = false;
+    for (uint32_t i = 0; i < d->n_shapes; ++i) if (d->shapes[i].bsdf == NORI_HIP_BSDF_SUBSURFACE) ctx->has_ss = true;
+    ctx->n_prims = d->n_prims; ctx->n_nodes = device_build ? ctx->lbvh.n_nodes : d->n_nodes;
     DevScene &sc = ctx->sc;
     sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
@@ -1579,7 +1655,10 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
     const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS, direct = ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS;
-    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced) || mats || direct) {
+    // Scenes with images or subsurface shapes: the stages when the scene has subsurface shapes (their probe rays go through the trace
+    // stage) and a tree with inner nodes, else the single kernel (image lookups on a few dozen primitives: measured faster).
+    const bool ext_stages = ctx->has_ss && ctx->wide && ctx->d_nodes4 != nullptr && ctx->merge_trace;
+    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced && !ext_stages) || (ctx->has_ss && !ext_stages) || mats || direct) {
         // single persistent kernel with per-lane path regeneration
         unsigned long long chunks = (job.total + MEGA_THREADS - 1) / MEGA_THREADS;
         const int MW = ctx->mega_waves;
@@ -1618,7 +1697,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         hipFree(ctx->pool_mem); hipFree(ctx->d_qlive); ctx->pool_mem = nullptr; ctx->d_qlive = nullptr; ctx->pool_alloc = 0;
         const size_t PA = ((size_t) P + 63) / 64 * 64, PB = ((PA / 2 + 63) / 64) * 64 + 64;
         DevBufs guard; float4 *mem = nullptr; unsigned int *ql = nullptr;
-        HIPCHK(guard.get(mem, (PA + PB) * 10 * sizeof(float4)));
+        HIPCHK(guard.get(mem, (PA + PB) * ND_POOL_ARRAYS * sizeof(float4)));
         HIPCHK(guard.get(ql, PA * 4));
         // ray ordering (k_ray_keys + radix sort): two key and two slot-number arrays and the sort's workspace
         hipFree(ctx->d_sort); ctx->d_sort = nullptr;
@@ -1630,8 +1709,9 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         auto carve = [](Pool &pl, float4 *base, size_t n) {
             pl.ray_o = base; pl.ray_d = base + n; pl.hit = (uint4 *) (base + 2 * n); pl.thr = base + 3 * n; pl.li = base + 4 * n;
             pl.rng = (uint4 *) (base + 5 * n); pl.pix = base + 6 * n; pl.sh_o = base + 7 * n; pl.sh_d = base + 8 * n; pl.sh_c = base + 9 * n;
+            pl.sv_o = base + 10 * n; pl.sv_d = base + 11 * n; pl.sv_h = (uint4 *) (base + 12 * n);
         };
-        carve(ctx->pool, mem, PA); carve(ctx->pool_b, mem + 10 * PA, PB);
+        carve(ctx->pool, mem, PA); carve(ctx->pool_b, mem + ND_POOL_ARRAYS * PA, PB);
     }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     WfCounters *c = ctx->d_cnt;
@@ -1690,7 +1770,9 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             }
             if (ctx->merge_trace) {
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
-                if (wide) {
+                if (wide && ctx->has_ss) {
+                    hipLaunchKernelGGL(k_trace_pool4_masked, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
+                } else if (wide) {
                     void (*k4)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *, const unsigned int *) =
                         ctx->profile ? (spec ? k_trace_pool4<true, true> : k_trace_pool4<true, false>) : (spec ? k_trace_pool4<false, true> : k_trace_pool4<false, false>);
                     hipLaunchKernelGGL(k4, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
@@ -1720,7 +1802,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
                 const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u)));
-                if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, true>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide) hipLaunchKernelGGL((k_finish<false, true>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
