@@ -1288,43 +1288,52 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     return NORI_HIP_OK;
 }
 
-// The uploaded binary tree as four-box nodes (Trav::box_step4): every inner node at an even depth with its inner children
-// opened, slots in the binary tree's depth-first order (left-left, left-right, right-left, right-right), valid slots first.
-// Also the check the kernels rely on: every node is reached once (no cycles, no shared subtrees) and the depth fits the stack.
-// out: 32 floats per node; depth: levels of inner nodes of the binary tree.
-static int collapse_host(const std::vector<NoriHipNode> &nodes, uint32_t root, std::vector<float> &out, uint32_t &root4, uint32_t &depth) {
-    out.clear(); depth = 0; root4 = root;
+// The uploaded binary tree as four-box nodes (Trav::box_step4).  A four-box node starts from a binary inner node's two children
+// and, while it has a free slot, opens the inner child with the largest box surface in place, so the slots stay in the binary
+// tree's depth-first order (the order the reference visits them in, src/bvh.cpp:425-431); the inner children left become four-box
+// nodes themselves (breadth-first numbering: the top of the tree comes first).  Also the check the kernels rely on: every node is
+// reached once (no cycles, no shared subtrees).  out: 32 floats per node; depth: levels of inner nodes of the binary tree;
+// depth4: levels of four-box nodes.
+static int collapse_host(const std::vector<NoriHipNode> &nodes, uint32_t root, std::vector<float> &out, uint32_t &root4, uint32_t &depth, uint32_t &depth4) {
+    out.clear(); depth = 0; depth4 = 0; root4 = root;
     if (root & NORI_HIP_LEAF_BIT) return NORI_HIP_OK;
-    struct Item { uint32_t bin, level; };
-    std::vector<Item> queue; queue.push_back({root, 0});                     // binary nodes that become four-box nodes, in breadth-first order
+    struct Item { uint32_t bin, level, level4; };
+    std::vector<Item> queue; queue.push_back({root, 0, 0});
     std::vector<unsigned char> seen(nodes.size(), 0); seen[root] = 1;
     const float inf = __builtin_huge_valf();
-    auto visit = [&](uint32_t r) { if (seen[r]) return false; seen[r] = 1; return true; };
+    auto area = [](const float *mn, const float *mx) { const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2]; return dx * dy + dy * dz + dz * dx; };
     for (size_t k = 0; k < queue.size(); ++k) {
         const Item it = queue[k]; const NoriHipNode &w = nodes[it.bin];
-        float mn[4][3], mx[4][3]; uint32_t ref[4]; int m = 0;
-        for (int j = 0; j < 4; ++j) { ref[j] = NORI_HIP_NO_CHILD; for (int a = 0; a < 3; ++a) { mn[j][a] = inf; mx[j][a] = -inf; } }
-        depth = std::max(depth, it.level + 1);
+        float mn[4][3], mx[4][3]; uint32_t ref[4], lvl[4]; int m = 0;
+        for (int j = 0; j < 4; ++j) { ref[j] = NORI_HIP_NO_CHILD; lvl[j] = 0; for (int a = 0; a < 3; ++a) { mn[j][a] = inf; mx[j][a] = -inf; } }
+        depth = std::max(depth, it.level + 1); depth4 = std::max(depth4, it.level4 + 1);
         for (int side = 0; side < 2; ++side) {
             const uint32_t r = side ? w.right : w.left;
             if (r == NORI_HIP_NO_CHILD) continue;
-            if (r & NORI_HIP_LEAF_BIT) {
-                for (int a = 0; a < 3; ++a) { mn[m][a] = side ? w.rmin[a] : w.lmin[a]; mx[m][a] = side ? w.rmax[a] : w.lmax[a]; }
-                ref[m++] = r; continue;
+            for (int a = 0; a < 3; ++a) { mn[m][a] = side ? w.rmin[a] : w.lmin[a]; mx[m][a] = side ? w.rmax[a] : w.lmax[a]; }
+            lvl[m] = it.level + 1; ref[m++] = r;
+        }
+        while (m < 4) {
+            int best = -1; float best_area = -1.f;
+            for (int j = 0; j < m; ++j) if (!(ref[j] & NORI_HIP_LEAF_BIT)) { const float ar = area(mn[j], mx[j]); if (ar > best_area) { best_area = ar; best = j; } }
+            if (best < 0) break;
+            const uint32_t r = ref[best];
+            if (seen[r]) return fail(NORI_HIP_EINVAL, "node table is not a tree: node " + std::to_string(r) + " is reached twice");
+            seen[r] = 1;
+            const NoriHipNode &c = nodes[r]; const uint32_t cl = lvl[best] + 1;
+            depth = std::max(depth, cl);
+            if (c.right == NORI_HIP_NO_CHILD) {
+                for (int a = 0; a < 3; ++a) { mn[best][a] = c.lmin[a]; mx[best][a] = c.lmax[a]; }
+                ref[best] = c.left; lvl[best] = cl; continue;
             }
-            if (!visit(r)) return fail(NORI_HIP_EINVAL, "node table is not a tree: node " + std::to_string(r) + " is reached twice");
-            const NoriHipNode &c = nodes[r];
-            depth = std::max(depth, it.level + 2);
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const uint32_t r2 = s2 ? c.right : c.left;
-                if (r2 == NORI_HIP_NO_CHILD) continue;
-                for (int a = 0; a < 3; ++a) { mn[m][a] = s2 ? c.rmin[a] : c.lmin[a]; mx[m][a] = s2 ? c.rmax[a] : c.lmax[a]; }
-                if (r2 & NORI_HIP_LEAF_BIT) ref[m++] = r2;
-                else {
-                    if (!visit(r2)) return fail(NORI_HIP_EINVAL, "node table is not a tree: node " + std::to_string(r2) + " is reached twice");
-                    ref[m++] = (uint32_t) queue.size(); queue.push_back({r2, it.level + 2});
-                }
-            }
+            for (int j = m; j > best + 1; --j) { ref[j] = ref[j - 1]; lvl[j] = lvl[j - 1]; for (int a = 0; a < 3; ++a) { mn[j][a] = mn[j - 1][a]; mx[j][a] = mx[j - 1][a]; } }
+            for (int a = 0; a < 3; ++a) { mn[best][a] = c.lmin[a]; mx[best][a] = c.lmax[a]; mn[best + 1][a] = c.rmin[a]; mx[best + 1][a] = c.rmax[a]; }
+            ref[best] = c.left; ref[best + 1] = c.right; lvl[best] = lvl[best + 1] = cl; ++m;
+        }
+        for (int j = 0; j < m; ++j) if (!(ref[j] & NORI_HIP_LEAF_BIT)) {
+            if (seen[ref[j]]) return fail(NORI_HIP_EINVAL, "node table is not a tree: node " + std::to_string(ref[j]) + " is reached twice");
+            seen[ref[j]] = 1;
+            queue.push_back({ref[j], lvl[j], it.level4 + 1}); ref[j] = (uint32_t) queue.size() - 1;
         }
         const size_t base = out.size(); out.resize(base + 32, 0.f);
         for (int j = 0; j < 4; ++j) {
@@ -1410,7 +1419,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
         ctx->d_nodes4 = (float4 *) ctx->lbvh.nodes4; ctx->n_nodes4 = ctx->lbvh.n_nodes4; ctx->lbvh.nodes4 = nullptr;
         // up to three stack entries per four-box level: deeper trees are walked through their two-box nodes
-        if (3u * ((ctx->lbvh.depth + 1u) / 2u) > (uint32_t) (ND_STACK - 2)) { hipFree(ctx->d_nodes4); ctx->d_nodes4 = nullptr; ctx->n_nodes4 = 0; }
+        if (3u * ctx->lbvh.depth4 > (uint32_t) (ND_STACK - 2)) { hipFree(ctx->d_nodes4); ctx->d_nodes4 = nullptr; ctx->n_nodes4 = 0; }
         root = ctx->lbvh.root;
         for (int i = 0; i < 3; ++i) { root_min[i] = ctx->lbvh.root_min[i]; root_max[i] = ctx->lbvh.root_max[i]; }
     } else {
@@ -1433,10 +1442,10 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
             root = new_of[d->root];
         }
         if ((rc = upload(ctx->d_nodes, nodes.data(), d->n_nodes))) return rc;
-        std::vector<float> wide; uint32_t root4w = root, depth = 0;
-        if ((rc = collapse_host(nodes, root, wide, root4w, depth))) return rc;
+        std::vector<float> wide; uint32_t root4w = root, depth = 0, depth4 = 0;
+        if ((rc = collapse_host(nodes, root, wide, root4w, depth, depth4))) return rc;
         if (depth > (uint32_t) (ND_STACK - 2)) return fail(NORI_HIP_EINVAL, "tree depth " + std::to_string(depth) + " exceeds the traversal stack (" + std::to_string(ND_STACK - 2) + ")");
-        if (!wide.empty() && 3u * ((depth + 1u) / 2u) <= (uint32_t) (ND_STACK - 2)) {
+        if (!wide.empty() && 3u * depth4 <= (uint32_t) (ND_STACK - 2)) {
             float *w = nullptr;
             if ((rc = upload(w, wide.data(), wide.size()))) return rc;
             ctx->d_nodes4 = (float4 *) w; ctx->n_nodes4 = (uint32_t) (wide.size() / 32);

@@ -18,6 +18,7 @@ struct Result {
     double build_ms;               // device time of the whole build (HIP events)
     void *nodes4 = nullptr;        // the same tree as 128-byte four-box nodes (Trav::box_step4), hipMalloc'ed here, owned by the caller;
     uint32_t n_nodes4 = 0;         // null when the tree is one leaf.  Its root is node 0.
+    uint32_t depth4 = 0;           // levels of four-box nodes (a traversal pushes at most three entries per level)
 };
 
 // prims_in / shade_in: n records in any order (bit 31 of shape_flags ignored).  prims_out / shade_out: n records in

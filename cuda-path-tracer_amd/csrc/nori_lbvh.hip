@@ -219,42 +219,60 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t n_inner, const uint32_
 
 __global__ void k_mark_last(NoriHipPrim *pout, uint32_t pos) { pout[pos].shape_flags |= 0x80000000u; }
 
-// ---- four-box nodes (Trav::box_step4 in nori_device.h): every inner node at an even depth becomes a 128-byte node holding its
-// grandchildren (a child that is a leaf stays a child).  Works on the emitted nodes before they are packed.
-__global__ __launch_bounds__(256) void k_even(uint32_t n_inner, const uint32_t *used, const uint32_t *parent_inner, uint32_t *even) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_inner) return;
-    uint32_t d = 0;
-    if (used[i]) for (uint32_t cur = i; cur != 0u; cur = parent_inner[cur]) ++d;
-    even[i] = (used[i] && !(d & 1u)) ? 1u : 0u;
+// ---- four-box nodes (Trav::box_step4 in nori_device.h).  A four-box node starts from a binary inner node's two children and,
+// while it has a free slot, opens the inner child with the largest box surface (in place, so the slots stay in the binary tree's
+// depth-first order); children that are leaves stay.  The inner children left at the end become four-box nodes themselves.  Which
+// binary nodes those are depends on the choices above them, so the tree is converted level by level: `queue` holds the binary
+// nodes of one level, a count pass and a scan number their inner children, an emit pass writes the level's nodes and the next
+// level's queue.  Node numbers: level after level, within a level in queue order (deterministic).
+struct Slots4 { float mn[4][3], mx[4][3]; uint32_t ref[4]; int n; };
+__device__ __forceinline__ float box_area(const float *mn, const float *mx) {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return dx * dy + dy * dz + dz * dx;
 }
-__global__ __launch_bounds__(256) void k_collapse4(uint32_t n_inner, const uint32_t *even, const uint32_t *widx, const NoriHipNode *nodes, float4 *out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_inner || !even[i]) return;
+__device__ __forceinline__ void open_greedy(const NoriHipNode *nodes, uint32_t b, Slots4 &s) {
     const float inf = __builtin_huge_valf();
-    float mn[4][3], mx[4][3]; uint32_t ref[4]; int m = 0;
-    for (int k = 0; k < 4; ++k) { ref[k] = NORI_HIP_NO_CHILD; for (int a = 0; a < 3; ++a) { mn[k][a] = inf; mx[k][a] = -inf; } }
-    const NoriHipNode w = nodes[i];
+    for (int k = 0; k < 4; ++k) { s.ref[k] = NORI_HIP_NO_CHILD; for (int a = 0; a < 3; ++a) { s.mn[k][a] = inf; s.mx[k][a] = -inf; } }
+    s.n = 0;
+    const NoriHipNode w = nodes[b];
     for (int side = 0; side < 2; ++side) {
         const uint32_t r = side ? w.right : w.left;
         if (r == NORI_HIP_NO_CHILD) continue;
-        if (r & LB_LEAF) {
-            for (int a = 0; a < 3; ++a) { mn[m][a] = side ? w.rmin[a] : w.lmin[a]; mx[m][a] = side ? w.rmax[a] : w.lmax[a]; }
-            ref[m++] = r;
-        } else {
-            const NoriHipNode c = nodes[r];
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const uint32_t r2 = s2 ? c.right : c.left;
-                if (r2 == NORI_HIP_NO_CHILD) continue;
-                for (int a = 0; a < 3; ++a) { mn[m][a] = s2 ? c.rmin[a] : c.lmin[a]; mx[m][a] = s2 ? c.rmax[a] : c.lmax[a]; }
-                ref[m++] = (r2 & LB_LEAF) ? r2 : widx[r2];
-            }
-        }
+        for (int a = 0; a < 3; ++a) { s.mn[s.n][a] = side ? w.rmin[a] : w.lmin[a]; s.mx[s.n][a] = side ? w.rmax[a] : w.lmax[a]; }
+        s.ref[s.n++] = r;
     }
-    float4 *q = out + 8 * (size_t) widx[i];
-    q[0] = make_float4(mn[0][0], mn[1][0], mn[2][0], mn[3][0]); q[1] = make_float4(mn[0][1], mn[1][1], mn[2][1], mn[3][1]); q[2] = make_float4(mn[0][2], mn[1][2], mn[2][2], mn[3][2]);
-    q[3] = make_float4(mx[0][0], mx[1][0], mx[2][0], mx[3][0]); q[4] = make_float4(mx[0][1], mx[1][1], mx[2][1], mx[3][1]); q[5] = make_float4(mx[0][2], mx[1][2], mx[2][2], mx[3][2]);
-    q[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+    while (s.n < 4) {
+        int best = -1; float best_area = -1.f;
+        for (int k = 0; k < s.n; ++k) if (!(s.ref[k] & LB_LEAF)) { const float ar = box_area(s.mn[k], s.mx[k]); if (ar > best_area) { best_area = ar; best = k; } }
+        if (best < 0) break;
+        const NoriHipNode c = nodes[s.ref[best]];
+        if (c.right == NORI_HIP_NO_CHILD) {                                // (a node with one child: take the child in its place)
+            for (int a = 0; a < 3; ++a) { s.mn[best][a] = c.lmin[a]; s.mx[best][a] = c.lmax[a]; }
+            s.ref[best] = c.left; continue;
+        }
+        for (int k = s.n; k > best + 1; --k) { s.ref[k] = s.ref[k - 1]; for (int a = 0; a < 3; ++a) { s.mn[k][a] = s.mn[k - 1][a]; s.mx[k][a] = s.mx[k - 1][a]; } }
+        for (int a = 0; a < 3; ++a) { s.mn[best][a] = c.lmin[a]; s.mx[best][a] = c.lmax[a]; s.mn[best + 1][a] = c.rmin[a]; s.mx[best + 1][a] = c.rmax[a]; }
+        s.ref[best] = c.left; s.ref[best + 1] = c.right; s.n++;
+    }
+}
+__global__ __launch_bounds__(256) void k_wide_count(uint32_t n_level, const uint32_t *queue, const NoriHipNode *nodes, uint32_t *count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_level) return;
+    Slots4 s; open_greedy(nodes, queue[i], s);
+    uint32_t c = 0; for (int k = 0; k < s.n; ++k) if (!(s.ref[k] & LB_LEAF)) ++c;
+    count[i] = c;
+}
+__global__ __launch_bounds__(256) void k_wide_emit(uint32_t n_level, const uint32_t *queue, const NoriHipNode *nodes, const uint32_t *offset, uint32_t level_base, uint32_t next_base,
+                                                   uint32_t *next_queue, float4 *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_level) return;
+    Slots4 s; open_greedy(nodes, queue[i], s);
+    uint32_t o = offset[i];
+    for (int k = 0; k < s.n; ++k) if (!(s.ref[k] & LB_LEAF)) { next_queue[o] = s.ref[k]; s.ref[k] = next_base + o; ++o; }
+    float4 *q = out + 8 * (size_t) (level_base + i);
+    q[0] = make_float4(s.mn[0][0], s.mn[1][0], s.mn[2][0], s.mn[3][0]); q[1] = make_float4(s.mn[0][1], s.mn[1][1], s.mn[2][1], s.mn[3][1]); q[2] = make_float4(s.mn[0][2], s.mn[1][2], s.mn[2][2], s.mn[3][2]);
+    q[3] = make_float4(s.mx[0][0], s.mx[1][0], s.mx[2][0], s.mx[3][0]); q[4] = make_float4(s.mx[0][1], s.mx[1][1], s.mx[2][1], s.mx[3][1]); q[5] = make_float4(s.mx[0][2], s.mx[1][2], s.mx[2][2], s.mx[3][2]);
+    q[6] = make_float4(__uint_as_float(s.ref[0]), __uint_as_float(s.ref[1]), __uint_as_float(s.ref[2]), __uint_as_float(s.ref[3]));
     q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -380,24 +398,35 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
     LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, used, new_index, (int) ni, stream));
     hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) used, (const uint32_t *) new_index, (const NoriHipNode *) nodes_tmp, nodes_out);
     LCHK(hipGetLastError());
-    // the same tree as four-box nodes
-    uint32_t *even, *widx;
-    LCHK(alloc((void **) &even, ni * 4)); LCHK(alloc((void **) &widx, ni * 4));
-    hipLaunchKernelGGL(k_even, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) used, (const uint32_t *) parent_inner, even);
-    LCHK(hipGetLastError());
-    LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, even, widx, (int) ni, stream));
-    uint32_t h_w[2];
-    LCHK(hipMemcpyAsync(&h_w[0], even + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
-    LCHK(hipMemcpyAsync(&h_w[1], widx + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
-    LCHK(hipStreamSynchronize(stream));
-    res.n_nodes4 = h_w[0] + h_w[1];
+    // the same tree as four-box nodes, level by level (on the emitted nodes before they are packed: `nodes_tmp`, root 0)
     {
+        uint32_t *qa, *qb, *cnt, *off; float4 *wide_tmp;
+        LCHK(alloc((void **) &qa, ni * 4)); LCHK(alloc((void **) &qb, ni * 4)); LCHK(alloc((void **) &cnt, ni * 4)); LCHK(alloc((void **) &off, ni * 4));
+        LCHK(alloc((void **) &wide_tmp, ni * 128));                               // at most one four-box node per binary node
+        const uint32_t zero = 0u;
+        LCHK(hipMemcpyAsync(qa, &zero, 4, hipMemcpyHostToDevice, stream));
+        uint32_t n_level = 1, base = 0, levels = 0;
+        while (n_level > 0) {
+            const unsigned lb = (n_level + 255u) / 256u;
+            hipLaunchKernelGGL(k_wide_count, dim3(lb), dim3(256), 0, stream, n_level, (const uint32_t *) qa, (const NoriHipNode *) nodes_tmp, cnt);
+            LCHK(hipGetLastError());
+            LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt, off, (int) n_level, stream));
+            hipLaunchKernelGGL(k_wide_emit, dim3(lb), dim3(256), 0, stream, n_level, (const uint32_t *) qa, (const NoriHipNode *) nodes_tmp, (const uint32_t *) off, base, base + n_level, qb, wide_tmp);
+            LCHK(hipGetLastError());
+            uint32_t h2[2];
+            LCHK(hipMemcpyAsync(&h2[0], cnt + (n_level - 1), 4, hipMemcpyDeviceToHost, stream));
+            LCHK(hipMemcpyAsync(&h2[1], off + (n_level - 1), 4, hipMemcpyDeviceToHost, stream));
+            LCHK(hipStreamSynchronize(stream));
+            base += n_level; n_level = h2[0] + h2[1]; ++levels;
+            std::swap(qa, qb);
+            if (base + (size_t) n_level > ni) { err = "lbvh: four-box conversion overran its node bound"; cleanup(); return NORI_HIP_EDEVICE; }
+        }
+        res.n_nodes4 = base; res.depth4 = levels;
         void *n4 = nullptr;
         LCHK(hipMalloc(&n4, (size_t) std::max<uint32_t>(res.n_nodes4, 1u) * 128));       // owned by the caller from here on
         res.nodes4 = n4;
+        LCHK(hipMemcpyAsync(n4, wide_tmp, (size_t) res.n_nodes4 * 128, hipMemcpyDeviceToDevice, stream));
     }
-    hipLaunchKernelGGL(k_collapse4, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) even, (const uint32_t *) widx, (const NoriHipNode *) nodes_tmp, (float4 *) res.nodes4);
-    LCHK(hipGetLastError());
     uint32_t h_last[2];
     LCHK(hipMemcpyAsync(&h_last[0], used + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
     LCHK(hipMemcpyAsync(&h_last[1], new_index + (ni - 1), 4, hipMemcpyDeviceToHost, stream));
