@@ -104,6 +104,9 @@ struct DevScene {
     NoriHipCamera cam;
     float inv_w, inv_h;
     int border, film_cols;
+    NoriHipEnvMap env;                 // environment emitter (env.texture = 0: none)
+    const float *env_cdf;              // normalised CDF over the env_h x env_w (u, v) cells of the environment map, env_h * env_w + 1 entries
+    uint32_t env_w, env_h;
     const float *filt_table;           // null: the fork's single-pixel film add.  Else the 33-entry tabulated reconstruction filter
     float filt_radius, filt_lookup;    //       of ImageBlock::init (src/block.cpp:54-64) for the filter-weighted splat (:113-128)
 };
@@ -790,6 +793,47 @@ __device__ __forceinline__ F3 emitter_sample(const DevScene &sc, const NoriHipEm
     return f3(0.f);
 }
 
+// ---- environment emitter (cuda/nori/spheremap.cpp.cu; sampling and density are this library's, see NoriHipEnvMap) -------------
+__device__ __forceinline__ F2 env_uv(const DevScene &sc, F3 dir) {        // SphereMap::eval's mapping, :64-67
+    const float *f = sc.env.frame;
+    F3 p = f3(dot(dir, f3(f[0], f[1], f[2])), dot(dir, f3(f[3], f[4], f[5])), dot(dir, f3(f[6], f[7], f[8])));
+    float z = p.z < -1.f ? -1.f : p.z > 1.f ? 1.f : p.z;
+    return f2(acosf(z) / ND_PI, (atan2f(p.y, p.x) + ND_PI) / (2 * ND_PI));
+}
+__device__ __forceinline__ F3 env_eval(const DevScene &sc, F3 dir) {
+    F3 c = tex_color(sc, sc.textures[sc.env.texture - 1], env_uv(sc, dir));
+    return c * sc.env.brightness;
+}
+// solid-angle density of env_sample at `dir`: cell probability / (cell size in (theta, phi) * sin theta)
+__device__ __forceinline__ float env_pdf(const DevScene &sc, F3 dir) {
+    F2 uv = env_uv(sc, dir);
+    int i = (int) (uv.x * (float) sc.env_h), j = (int) (uv.y * (float) sc.env_w);
+    i = i < 0 ? 0 : i > (int) sc.env_h - 1 ? (int) sc.env_h - 1 : i; j = j < 0 ? 0 : j > (int) sc.env_w - 1 ? (int) sc.env_w - 1 : j;
+    const uint32_t k = (uint32_t) i * sc.env_w + (uint32_t) j;
+    const float p = sc.env_cdf[k + 1] - sc.env_cdf[k];
+    const float st = sinf(uv.x * ND_PI);
+    if (!(st > 1e-6f)) return 0.f;
+    return p * (float) sc.env_w * (float) sc.env_h / (2.0f * ND_PI * ND_PI * st);
+}
+// a direction drawn from the table: the cell by the CDF (DiscretePDF::sampleReuse), uniform inside the cell
+__device__ __forceinline__ F3 env_sample(const DevScene &sc, F2 sample, float &pdf) {
+    const uint32_t n = sc.env_w * sc.env_h;
+    uint32_t lo = 0, len = n + 1;
+    while (len > 0) { uint32_t half = len >> 1; if (sc.env_cdf[lo + half] < sample.x) { lo += half + 1; len -= half + 1; } else len = half; }
+    int idx = (int) lo - 1; if (idx < 0) idx = 0; if (idx > (int) n - 1) idx = (int) n - 1;
+    const float c0 = sc.env_cdf[idx], c1 = sc.env_cdf[idx + 1];
+    float sx = (c1 > c0) ? (sample.x - c0) / (c1 - c0) : 0.5f; sx = sx < 0.f ? 0.f : sx > 0.999999f ? 0.999999f : sx;
+    const uint32_t i = (uint32_t) idx / sc.env_w, j = (uint32_t) idx % sc.env_w;
+    const float u = ((float) i + sx) / (float) sc.env_h, v = ((float) j + sample.y) / (float) sc.env_w;
+    const float theta = u * ND_PI, phi = v * 2 * ND_PI - ND_PI;
+    float st, ct, sp, cp; sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+    const float *f = sc.env.frame;
+    F3 l = f3(st * cp, st * sp, ct);
+    F3 d = (f3(f[0], f[1], f[2]) * l.x + f3(f[3], f[4], f[5]) * l.y) + f3(f[6], f[7], f[8]) * l.z;
+    pdf = (st > 1e-6f) ? (c1 - c0) * (float) sc.env_w * (float) sc.env_h / (2.0f * ND_PI * ND_PI * st) : 0.f;
+    return d;
+}
+
 // ---- one path, PathMisIntegrator::Li (src/pathMisIntegrator.cpp:18-168) ---------------------------------
 // State kept between bounces (what the reference keeps in locals across iterations of its while(true)).
 struct PathState {
@@ -797,6 +841,17 @@ struct PathState {
 };
 __device__ __forceinline__ void path_init(PathState &ps, const Ray &r) {
     ps.ray = r; ps.t = f3(1.0f); ps.li = f3(0.f); ps.last_bsdf_pdf = 1.0f; ps.last_delta = true;
+}
+// A ray that left the scene: the environment's radiance with the MIS weight of the BSDF sample that made the ray
+// (cuda/nori/pathMisIntegrator.cpp.cu:46-75).  Zero without an environment emitter.
+template <bool EXT>
+__device__ __forceinline__ F3 env_miss(const DevScene &sc, F3 dir, F3 t, float last_bsdf_pdf, bool last_delta) {
+    if (!EXT || !sc.env.texture) return f3(0.f);
+    F3 flight = env_eval(sc, dir);
+    float light_pdf = env_pdf(sc, dir);
+    float wmat = last_bsdf_pdf / (light_pdf + last_bsdf_pdf);
+    if (last_delta) wmat = 1.0f;
+    return (wmat > 0.0f) ? (wmat * t) * flight : f3(0.f);
 }
 // What the shading of one hit leaves behind for the shadow stage
 struct ShadeOut { bool end; bool has_shadow; Ray shadow; F3 contrib; };
@@ -884,6 +939,7 @@ __device__ __forceinline__ void ss_probe_ray(const DevScene &sc, const ShadeCtx 
     probe.d = d; probe.o = sf.p + fr.toWorld(f3(dx.x, dx.y, 0.f));
     probe.mint = -1e-3f; probe.maxt = nd_sqrt(dx.x * dx.x + dx.y * dx.y) + 1e-3f;
 }
+template <bool EXT = false>
 __device__ __forceinline__ void shade_finish(const DevScene &sc, PathState &ps, Pcg32 &rng, const ShadeCtx &cx, F3 op, const Frame &osh, ShadeOut &out) {
     const NoriHipShape &shp = sc.shapes[cx.sf.shape];
     const F3 wi_l = cx.wi_l, alb = cx.alb;
@@ -897,17 +953,31 @@ __device__ __forceinline__ void shade_finish(const DevScene &sc, PathState &ps, 
     float pick = rng.next1D();                                            // :114 (drawn for delta BSDFs too)
     if (!is_delta) {
         uint32_t n = sc.n_emitters;
-        uint32_t index = (uint32_t) floorf((float) n * pick); if (index > n - 1) index = n - 1;
-        const NoriHipEmitter &em = sc.emitters[index];
-        F3 lwi, ln, lp;
-        F3 liLoc = emitter_sample(sc, em, op, rng.next2D(), lwi, ln, lp, out.shadow);
+        // with an environment emitter there is one more light, picked with probability 1 / lights by a draw of its own
+        // (cuda/nori/pathMisIntegrator.cpp.cu:22-24, 176-184)
+        const bool has_env = EXT && sc.env.texture != 0u;
+        const uint32_t lights = n + (has_env ? 1u : 0u);
+        bool use_env = false;
+        if (has_env) { const float c = rng.next1D(); use_env = n == 0u || c > (float) (lights - 1u) / (float) lights; }
+        F3 lwi, liLoc; float lpdf;
+        if (use_env) {
+            F2 s = rng.next2D();
+            lwi = env_sample(sc, s, lpdf);
+            liLoc = (lpdf > 1e-6f) ? env_eval(sc, lwi) / lpdf : f3(0.f);
+            out.shadow.o = op; out.shadow.d = lwi; out.shadow.mint = ND_EPS; out.shadow.maxt = ND_INF;      // Ray3f(ref, wi, Epsilon, INFINITY), spheremap.cpp.cu:84
+        } else {
+            uint32_t index = (uint32_t) floorf((float) n * pick); if (index > n - 1) index = n - 1;
+            const NoriHipEmitter &em = sc.emitters[index];
+            F3 ln, lp;
+            liLoc = emitter_sample(sc, em, op, rng.next2D(), lwi, ln, lp, out.shadow);
+            lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), op, lp, ln, lwi);
+        }
         out.has_shadow = true;
         F3 wo_l = osh.toLocal(lwi);
         float bpdf = bsdf_pdf(shp, wi_l, wo_l);
-        float lpdf = emitter_pdf(shape_area_pdf(sc, sc.shapes[em.shape]), op, lp, ln, lwi);
         float wem = lpdf / (lpdf + bpdf);
         float cosS = dot(normalized(lwi), normalized(osh.n));
-        if (wem > 0) out.contrib = ((((ps.t * wem) * liLoc) * bsdf_eval(shp, alb, wi_l, wo_l)) * fabsf(cosS)) * (float) n;
+        if (wem > 0) out.contrib = ((((ps.t * wem) * liLoc) * bsdf_eval(shp, alb, wi_l, wo_l)) * fabsf(cosS)) * (float) lights;
     }
     if (!wo_valid || is_zero(f)) { out.end = true; return; }
     ps.ray.d = next_dir; ps.ray.o = op; ps.ray.mint = 1e-3f; ps.ray.maxt = ND_INF;
@@ -938,7 +1008,7 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
         }
         if (!found) { out.end = true; return; }
     }
-    shade_finish(sc, ps, rng, cx, op, osh, out);
+    shade_finish<EXT>(sc, ps, rng, cx, op, osh, out);
 }
 
 // A bounce that the wavefront pipeline left between its two halves: the hit `hit0` of ray `ray0` was shaded up to the roulette and
@@ -958,7 +1028,7 @@ __device__ __forceinline__ void shade_resume(const DevScene &sc, PathState &ps, 
     }
     if (!found) { out.end = true; return; }
     Surface so; surface_from_hit<EXT>(sc, probe, ph, so, false);
-    shade_finish(sc, ps, rng, cx, so.p, so.sh, out);
+    shade_finish<EXT>(sc, ps, rng, cx, so.p, so.sh, out);
 }
 
 // One iteration of the reference's bounce loop, run to completion by one lane.  Returns false when the path ended.
@@ -966,7 +1036,7 @@ template <bool EXT = false, typename StackT, typename NodesT>
 __device__ __forceinline__ bool path_bounce(const DevScene &sc, const NodesT &nodes, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     Hit hit;
     ctr.closest++;
-    if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+    if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) { ps.li = ps.li + env_miss<EXT>(sc, ps.ray.d, ps.t, ps.last_bsdf_pdf, ps.last_delta); return false; }
     ShadeOut so;
     shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
     if (so.has_shadow) {
@@ -983,7 +1053,7 @@ template <bool EXT = false, typename StackT, typename NodesT>
 __device__ __forceinline__ bool path_bounce_mats(const DevScene &sc, const NodesT &nodes, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     Hit hit;
     ctr.closest++;
-    if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) return false;
+    if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) { ps.li = ps.li + env_miss<EXT>(sc, ps.ray.d, ps.t, 1.0f, true); return false; }   // (no emitter sampling: weight 1)
     Surface sf;
     surface_from_hit<EXT>(sc, ps.ray, hit, sf, false);
     const NoriHipShape &shp = sc.shapes[sf.shape];

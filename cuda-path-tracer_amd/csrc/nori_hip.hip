@@ -129,6 +129,16 @@ __global__ __launch_bounds__(256) void k_bsdf_vectors(NoriHipShape b, size_t n, 
     o[0] = weight.x; o[1] = weight.y; o[2] = weight.z; o[3] = wo.x; o[4] = wo.y; o[5] = wo.z; o[6] = pdf; o[7] = ev.x; o[8] = ev.y; o[9] = ev.z;
     o[10] = is_delta ? 1.f : 0.f; o[11] = wo_valid ? 1.f : 0.f;
 }
+// environment emitter: the sampling weight of every (u, v) cell, (r + g + b) * sin(theta) at the cell's centre (plus a floor, so that
+// no direction with radiance has probability zero)
+__global__ __launch_bounds__(256) void k_env_weights(DevScene sc, uint32_t w, uint32_t h, float *weights) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= w * h) return;
+    const uint32_t i = k / w, j = k % w;
+    const float u = ((float) i + 0.5f) / (float) h, v = ((float) j + 0.5f) / (float) w;
+    const F3 c = tex_color(sc, sc.textures[sc.env.texture - 1], f2(u, v));
+    weights[k] = (c.x + c.y + c.z + 1e-4f) * sinf(u * ND_PI);
+}
 // n draws of pcg32.seed(state, seq) by one lane (known-answer test of the device sampler, ext/pcg32/pcg32-demo.out)
 __global__ void k_pcg32(uint64_t state, uint64_t seq, unsigned int n, uint32_t *out_u32, float *out_f32) {
     Pcg32 r; r.seed(state, seq);
@@ -450,7 +460,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         Hit ph; ph.pos = h.x; ph.t = __uint_as_float(h.y); ph.u = __uint_as_float(h.z); ph.v = __uint_as_float(h.w);
                         Surface sp; surface_from_hit<EXT>(sc, probe, ph, sp, false);
                         so.end = false; so.has_shadow = false; so.contrib = f3(0.f);
-                        shade_finish(sc, ps, rng, cx, sp.p, sp.sh, so);
+                        shade_finish<EXT>(sc, ps, rng, cx, sp.p, sp.sh, so);
                         shaded = true;
                     } else {
                         // the probe left the shape: the reference draws another one (src/pathMisIntegrator.cpp:88-90), up to ND_PROBE_TRIES here
@@ -465,6 +475,9 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                             ended = false;
                         }
                     }
+                } else if (EXT && !(flags & PF_ENDING) && h.x == 0xffffffffu) {
+                    // the ray left the scene: the environment emitter, if there is one (the path ends either way)
+                    ps.li = ps.li + env_miss<EXT>(sc, f3(rd.x, rd.y, rd.z), ps.t, ps.last_bsdf_pdf, ps.last_delta);
                 } else if (!(flags & PF_ENDING) && h.x != 0xffffffffu) {
                     ps.ray.o = f3(ro.x, ro.y, ro.z); ps.ray.mint = ro.w; ps.ray.d = f3(rd.x, rd.y, rd.z); ps.ray.maxt = rd.w;
                     Hit hit; hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
@@ -482,7 +495,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(PF_ACTIVE | PF_PROBE | (flags & PF_LAST_DELTA)));
                         ended = false;
-                    } else { shade_finish(sc, ps, rng, cx, cx.sf.p, cx.sf.sh, so); shaded = true; }
+                    } else { shade_finish<EXT>(sc, ps, rng, cx, cx.sf.p, cx.sf.sh, so); shaded = true; }
                 }
                 if (shaded) {
                     flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
@@ -900,6 +913,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
                         resume = false; alive = true;
                     } else {
+                        if (EXT && !(flags & PF_ENDING) && sc.env.texture) {       // the slot's last ray left the scene: the environment emitter
+                            const float4 rd = pool.ray_d[slot], T = pool.thr[slot];
+                            ps.li = ps.li + env_miss<EXT>(sc, f3(rd.x, rd.y, rd.z), f3(T.x, T.y, T.z), T.w, (flags & PF_LAST_DELTA) != 0);
+                        }
                         const unsigned int pxy = __float_as_uint(P.z);
                         if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
                     }
@@ -921,7 +938,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (!(WIDE ? trace4<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims))) ps.li = ps.li + so.contrib;
             }
             bool go_on = !so.end;
-            if (go_on) { ctr.closest++; go_on = WIDE ? trace4<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims) : trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims); }
+            if (go_on) {
+                ctr.closest++; go_on = WIDE ? trace4<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims) : trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims);
+                if (!go_on) ps.li = ps.li + env_miss<EXT>(sc, ps.ray.d, ps.t, ps.last_bsdf_pdf, ps.last_delta);
+            }
             if (!go_on) {
                 const unsigned int pxy = __float_as_uint(P.z);
                 if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
@@ -1108,6 +1128,7 @@ struct NoriHipContext {
     NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
     NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
+    float *d_env_cdf = nullptr;       // environment emitter: CDF over its (u, v) cells
     float *d_filt = nullptr; float filt_radius = 0.f;   // nori_hip_set_film_filter (kept across scene uploads)
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
     bool has_ss = false;              // ... subsurface shapes: the wavefront pipeline traces their probe rays in its trace stage
@@ -1168,6 +1189,7 @@ struct NoriHipContext {
     }
     void free_scene() {
         hipFree(d_nodes4); d_nodes4 = nullptr; n_nodes4 = 0;
+        hipFree(d_env_cdf); d_env_cdf = nullptr;
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         hipFree(d_textures); hipFree(d_tex_data); d_textures = nullptr; d_tex_data = nullptr; ext = false;
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
@@ -1387,6 +1409,11 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
             return fail(NORI_HIP_EINVAL, "texture " + std::to_string(i) + " lies outside tex_data");
         if (t.scale[0] == 0.f || t.scale[1] == 0.f) return fail(NORI_HIP_EINVAL, "texture scale is zero");
     }
+    if (d->env.texture) {
+        if (d->env.texture > d->n_textures || d->textures[d->env.texture - 1].kind != NORI_HIP_TEX_COLOR) return fail(NORI_HIP_EINVAL, "environment emitter names no colour image");
+        if (!(d->env.brightness >= 0.f)) return fail(NORI_HIP_EINVAL, "environment emitter: negative brightness");
+        ext = true;
+    }
     for (uint32_t i = 0; i < d->n_emitters; ++i) {
         const NoriHipEmitter &e = d->emitters[i];
         if (e.shape < 0 || e.shape >= (int32_t) d->n_shapes) return fail(NORI_HIP_EINVAL, "emitter shape index out of range");
@@ -1481,6 +1508,29 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     sc.border = ctx->border; sc.film_cols = ctx->film_cols;
     HIPCHK(hipMalloc((void **) &ctx->d_film, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4)));
     HIPCHK(hipMemset(ctx->d_film, 0, (size_t) ctx->film_rows * ctx->film_cols * sizeof(float4)));
+    sc.env = d->env; sc.env_cdf = nullptr; sc.env_w = sc.env_h = 0;
+    if (d->env.texture) {
+        // the sampling table of the environment emitter: one cell per texel of its image, weights evaluated on the device through
+        // the same lookup the integrator uses (scale, delta and filtering included), summed in double on the host
+        const NoriHipTexture &t = d->textures[d->env.texture - 1];
+        const uint32_t w = t.width, h = t.height; const size_t n = (size_t) w * h;
+        if (n >= (1u << 28)) return fail(NORI_HIP_EINVAL, "environment image too large");
+        sc.env_w = w; sc.env_h = h;
+        DevBufs bufs; float *d_wt = nullptr;
+        HIPCHK(bufs.get(d_wt, n * 4));
+        hipLaunchKernelGGL(k_env_weights, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, w, h, d_wt);
+        HIPCHK(hipGetLastError());
+        std::vector<float> wt(n), cdf(n + 1);
+        HIPCHK(hipMemcpyAsync(wt.data(), d_wt, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        double sum = 0; for (size_t k = 0; k < n; ++k) sum += wt[k];
+        if (!(sum > 0)) return fail(NORI_HIP_EINVAL, "environment image has no weight");
+        double acc = 0; cdf[0] = 0.f;
+        for (size_t k = 0; k < n; ++k) { acc += wt[k]; cdf[k + 1] = (float) (acc / sum); }
+        cdf[n] = 1.0f;
+        if ((rc = upload(ctx->d_env_cdf, cdf.data(), n + 1))) return rc;
+        sc.env_cdf = ctx->d_env_cdf;
+    }
     ctx->have_scene = true;
     return NORI_HIP_OK;
 }
@@ -1563,7 +1613,7 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     SCENECHK(ctx);
     if (n == 0) return NORI_HIP_OK;
     if (!states || !seqs || !rgb || ((px == nullptr) != (py == nullptr))) return fail(NORI_HIP_EINVAL, "null buffer");
-    if (ctx->sc.n_emitters == 0 && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
+    if (ctx->sc.n_emitters == 0 && !ctx->sc.env.texture && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
     DevBufs bufs; int32_t *d_px = nullptr, *d_py = nullptr; uint64_t *d_st = nullptr, *d_sq = nullptr; NoriHipRay *d_rays = nullptr; float *d_rgb = nullptr;
     if (px) { HIPCHK(bufs.get(d_px, n * 4)); HIPCHK(hipMemcpyAsync(d_px, px, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
     if (py) { HIPCHK(bufs.get(d_py, n * 4)); HIPCHK(hipMemcpyAsync(d_py, py, n * 4, hipMemcpyHostToDevice, ctx->stream)); }
@@ -1637,7 +1687,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const int W = ctx->sc.cam.width, H = ctx->sc.cam.height;
     if (!tiles_xyxy || n_tiles < 1 || n_tiles > ND_MAX_TILES) return fail(NORI_HIP_EINVAL, "tile list is null, empty or longer than " + std::to_string(ND_MAX_TILES));
     if (spp_begin < 0 || spp_end <= spp_begin) return fail(NORI_HIP_EINVAL, "empty sample range");
-    if (ctx->sc.n_emitters == 0 && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
+    if (ctx->sc.n_emitters == 0 && !ctx->sc.env.texture && !(ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS)) return fail(NORI_HIP_ESTATE, "path_mis needs at least one emitter");
     RenderJob job; job.spp_begin = spp_begin; job.nspp = spp_end - spp_begin; job.total = 0; job.n_tiles = n_tiles;
     job.tiles = nullptr; job.patch_first = nullptr;
     std::vector<int> h_tiles((size_t) 4 * n_tiles); std::vector<unsigned int> h_first((size_t) n_tiles + 1, 0u);

@@ -290,6 +290,12 @@ void flattenScene(const Scene *scene, FlatScene &out) {
     d.n_textures = (uint32_t) out.textures.size(); d.textures = out.textures.empty() ? nullptr : out.textures.data();
     d.n_tex_bytes = out.tex_data.size(); d.tex_data = out.tex_data.empty() ? nullptr : out.tex_data.data();
     scene->getCamera()->describe(d.camera);
+    if (const EnvironmentMap *env = scene->getEnvMap()) {
+        env->describe(d.env);
+        d.env.texture = addImage(env->image());
+        d.n_textures = (uint32_t) out.textures.size(); d.textures = out.textures.data();
+        d.n_tex_bytes = out.tex_data.size(); d.tex_data = out.tex_data.data();
+    }
 }
 
 } // namespace nori

@@ -33,7 +33,7 @@ std::string NoriObject::classTypeName(EClassType type) {
     switch (type) {
         case EScene: return "scene"; case EMesh: return "mesh"; case ETexture: return "texture"; case EBSDF: return "bsdf";
         case EEmitter: return "emitter"; case ECamera: return "camera"; case EIntegrator: return "integrator"; case ESampler: return "sampler";
-        case ETest: return "test"; case EReconstructionFilter: return "rfilter"; case ENormalModifier: return "normalModifier";
+        case ETest: return "test"; case EReconstructionFilter: return "rfilter"; case ENormalModifier: return "normalModifier"; case EEnvMap: return "enviromentMap";
         case EPhaseFunction: return "phase"; case EMedium: return "medium"; default: return "<unknown>";
     }
 }
@@ -200,7 +200,7 @@ NoriObject *loadFromXML(const std::string &filename) {
         {"scene", NoriObject::EScene}, {"mesh", NoriObject::EMesh}, {"texture", NoriObject::ETexture}, {"bsdf", NoriObject::EBSDF},
         {"emitter", NoriObject::EEmitter}, {"camera", NoriObject::ECamera}, {"medium", NoriObject::EMedium}, {"phase", NoriObject::EPhaseFunction},
         {"integrator", NoriObject::EIntegrator}, {"sampler", NoriObject::ESampler}, {"rfilter", NoriObject::EReconstructionFilter},
-        {"test", NoriObject::ETest}, {"normalModifier", NoriObject::ENormalModifier},
+        {"test", NoriObject::ETest}, {"normalModifier", NoriObject::ENormalModifier}, {"enviromentMap", NoriObject::EEnvMap} /* the fork's spelling, cuda/nori/parser.cpp:118 */,
         {"boolean", EBoolean}, {"integer", EInteger}, {"float", EFloat}, {"string", EString}, {"point", EPoint}, {"vector", EVector},
         {"color", EColor}, {"transform", ETransform}, {"translate", ETranslate}, {"matrix", EMatrix}, {"rotate", ERotate}, {"scale", EScale}, {"lookat", ELookAt}};
 

@@ -60,7 +60,7 @@ public:
     ~PathMisHip() override { if (m_group) nori_hip_group_destroy(m_group); else if (m_ctx) nori_hip_destroy(m_ctx); }
     void preprocess(const Scene *scene) override {
         flattenScene(scene, m_flat);
-        if (m_flat.desc.n_emitters == 0 && m_kind == NORI_HIP_INTEGRATOR_PATH_MIS) throw NoriException("path_mis: the scene has no emitters");
+        if (m_flat.desc.n_emitters == 0 && !m_flat.desc.env.texture && m_kind == NORI_HIP_INTEGRATOR_PATH_MIS) throw NoriException("path_mis: the scene has no emitters");
         const bool grouped = m_allDevices || !m_devices.empty();
         if (grouped && !m_group) {
             if (m_allDevices) {

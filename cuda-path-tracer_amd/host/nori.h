@@ -121,7 +121,7 @@ private:
 class NoriObject {
 public:
     enum EClassType { EScene = 0, EMesh, ETexture, EBSDF, EPhaseFunction, EEmitter, EMedium, ECamera, EIntegrator, ESampler, ETest,
-                      EReconstructionFilter, ENormalModifier, EClassTypeCount };
+                      EReconstructionFilter, ENormalModifier, EEnvMap, EClassTypeCount };
     virtual ~NoriObject() {}
     virtual EClassType getClassType() const = 0;
     virtual void addChild(NoriObject *child);

@@ -263,6 +263,36 @@ private:
 };
 NORI_REGISTER_CLASS(ImageColorTexture, "image_color")
 
+/// sphereMap (cuda/nori/spheremap.cpp.cu:31-42): a lat-long image around the scene; takes image_color's properties (filename, scale,
+/// delta, lookup) plus brightness_factor and origin (the polar axis, default +y)
+class SphereMap : public EnvironmentMap {
+public:
+    explicit SphereMap(const PropertyList &p) {
+        imageCommon(p, m_img, NORI_HIP_TEX_COLOR);
+        rgbaTexels(p.getString("filename"), m_img);
+        m_bright = p.getFloat("brightness_factor", 1.0f);
+        m_origin = p.getVector3("origin", Vector3f(0.f, 1.f, 0.f));
+        const float len = std::sqrt(m_origin.x * m_origin.x + m_origin.y * m_origin.y + m_origin.z * m_origin.z);
+        if (!(len > 0.f)) throw NoriException("sphereMap: origin must not be the zero vector");
+        m_origin = Vector3f(m_origin.x / len, m_origin.y / len, m_origin.z / len);
+    }
+    const ImageData *image() const override { return &m_img; }
+    void describe(NoriHipEnvMap &out) const override {
+        out.brightness = m_bright;
+        // Frame(n): coordinateSystem (src/common.cpp:274-283)
+        const Vector3f a = m_origin; Vector3f c;
+        if (std::fabs(a.x) > std::fabs(a.y)) { float inv = 1.0f / std::sqrt(a.x * a.x + a.z * a.z); c = Vector3f(a.z * inv, 0.0f, -a.x * inv); }
+        else { float inv = 1.0f / std::sqrt(a.y * a.y + a.z * a.z); c = Vector3f(0.0f, a.z * inv, -a.y * inv); }
+        const Vector3f s(c.y * a.z - c.z * a.y, c.z * a.x - c.x * a.z, c.x * a.y - c.y * a.x);
+        const float f[9] = {s.x, s.y, s.z, c.x, c.y, c.z, a.x, a.y, a.z};
+        for (int i = 0; i < 9; ++i) out.frame[i] = f[i];
+    }
+    std::string toString() const override { return "EnviromentLight[]"; }
+private:
+    ImageData m_img; float m_bright; Vector3f m_origin;
+};
+NORI_REGISTER_CLASS(SphereMap, "sphereMap")
+
 /// bump_map (cuda/nori/bumpMap.cpp.cu:31-115): grey image -> Sobel gradients in x and y, 16-bit signed
 class BumpMap : public NormalModifier {
 public:
@@ -508,7 +538,7 @@ NORI_REGISTER_CLASS(Independent, "independent")
 
 // ---- scene ------------------------------------------------------------------------------------------------
 Scene::Scene(const PropertyList &) { m_bvh = new BVH(); }
-Scene::~Scene() { delete m_bvh; delete m_sampler; delete m_camera; delete m_integrator; for (auto e : m_emitters) delete e; }
+Scene::~Scene() { delete m_bvh; delete m_sampler; delete m_camera; delete m_integrator; delete m_envmap; for (auto e : m_emitters) delete e; }
 void Scene::activate() {
     if (!m_integrator) throw NoriException("No integrator was specified!");
     if (!m_integrator->buildsOwnBVH()) m_bvh->build();      // src/scene.cpp:42-43; otherwise the device builds a tree at preprocess()
@@ -522,6 +552,7 @@ void Scene::addChild(NoriObject *obj) {
         case ESampler: if (m_sampler) throw NoriException("There can only be one sampler per scene!"); m_sampler = static_cast<Sampler *>(obj); break;
         case ECamera: if (m_camera) throw NoriException("There can only be one camera per scene!"); m_camera = static_cast<Camera *>(obj); break;
         case EIntegrator: if (m_integrator) throw NoriException("There can only be one integrator per scene!"); m_integrator = static_cast<Integrator *>(obj); break;
+        case EEnvMap: if (m_envmap) throw NoriException("There can only be one Enviroment map per scene"); m_envmap = static_cast<EnvironmentMap *>(obj); break;   // cuda/nori/scene.cpp:116-120
         default: throw NoriException::format("Scene::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
     }
 }

@@ -159,6 +159,14 @@ private:
     std::vector<Node32> m_nodes; std::vector<uint32_t> m_indices; BoundingBox3f m_bbox; double m_buildSeconds = 0; bool m_owns = true;
 };
 
+/// <enviromentMap> (cuda/include/nori/enviromentmap.h): an emitter around the scene
+class EnvironmentMap : public NoriObject {
+public:
+    EClassType getClassType() const override { return EEnvMap; }
+    virtual const ImageData *image() const = 0;
+    virtual void describe(NoriHipEnvMap &out) const = 0;     // brightness and frame; the texture index is the flattener's
+};
+
 class Scene;
 /// Integrator plugin interface (include/nori/integrator.h:35-62).  The reference's per-ray Li() cannot feed a GPU;
 /// the batch entry render() is what the (headless) render driver calls after preprocess().
@@ -195,10 +203,11 @@ public:
     Sampler *getSampler() { return m_sampler; }
     const std::vector<Shape *> &getShapes() const { return m_shapes; }
     const std::vector<Emitter *> &getLights() const { return m_emitters; }
+    const EnvironmentMap *getEnvMap() const { return m_envmap; }          // cuda/include/nori/scene.h:79
     std::string toString() const override;
 private:
     std::vector<Shape *> m_shapes; std::vector<Emitter *> m_emitters;
-    Integrator *m_integrator = nullptr; Sampler *m_sampler = nullptr; Camera *m_camera = nullptr; BVH *m_bvh = nullptr;
+    Integrator *m_integrator = nullptr; Sampler *m_sampler = nullptr; Camera *m_camera = nullptr; BVH *m_bvh = nullptr; EnvironmentMap *m_envmap = nullptr;
 };
 
 /// Owns the arrays a NoriHipSceneDesc points into

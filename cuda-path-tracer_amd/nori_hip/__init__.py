@@ -21,12 +21,16 @@ class Camera(C.Structure):
                 ("near_clip", C.c_float), ("far_clip", C.c_float), ("filter_radius", C.c_float)]
 
 
+class EnvMap(C.Structure):
+    _fields_ = [("texture", C.c_uint32), ("brightness", C.c_float), ("frame", C.c_float * 9)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("nodes", C.c_void_p), ("n_prims", C.c_uint32), ("prims", C.c_void_p), ("shade_prims", C.c_void_p),
                 ("root", C.c_uint32), ("root_min", C.c_float * 3), ("root_max", C.c_float * 3),
                 ("n_shapes", C.c_uint32), ("shapes", C.c_void_p), ("n_emitters", C.c_uint32), ("emitters", C.c_void_p),
                 ("n_cdf", C.c_uint32), ("cdf", C.c_void_p), ("n_light_prims", C.c_uint32), ("light_prims", C.c_void_p), ("camera", Camera),
-                ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_tex_bytes", C.c_uint64), ("tex_data", C.c_void_p)]
+                ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_tex_bytes", C.c_uint64), ("tex_data", C.c_void_p), ("env", EnvMap)]
 
 
 class Stats(C.Structure):

@@ -131,6 +131,22 @@ typedef struct NoriHipCamera {
     float    filter_radius;        /* reconstruction filter radius: film border = ceil(radius - 0.5) (src/block.cpp:57) */
 } NoriHipCamera;
 
+/*
+ * Environment emitter: a lat-long image around the scene (the CUDA fork's <enviromentMap type="sphereMap">,
+ * cuda/nori/spheremap.cpp.cu, cuda/include/nori/scene.h:79; the CPU renderer has none).  A ray that leaves the scene in world
+ * direction d sees textures[texture - 1] at uv = (acos(p.z) / pi, (atan2(p.y, p.x) + pi) / (2 pi)), p = d in the frame below, times
+ * `brightness` (SphereMap::eval, :61-70), with the MIS weight of the last BSDF sample as for a hit emitter
+ * (cuda/nori/pathMisIntegrator.cpp.cu:46-75); emitter sampling picks the map with probability 1 / (emitters + 1) (:176-184).
+ * The fork's own sample() / pdf() are unfinished (pdf is marked "todo", sample returns radiance that was never divided by a
+ * density and builds directions that do not invert eval's mapping): this library samples the map's (u, v) cells in proportion to
+ * (r + g + b) * sin(theta) from a table it builds at upload, with the matching solid-angle density.  Parity unpinned.
+ */
+typedef struct NoriHipEnvMap {
+    uint32_t texture;              /* 0: no environment emitter; k: textures[k-1] (NORI_HIP_TEX_COLOR) */
+    float    brightness;           /* brightness_factor */
+    float    frame[9];             /* SphereMap::origin = Frame(origin vector): s, t, n (cuda/nori/spheremap.cpp.cu:33-34) */
+} NoriHipEnvMap;
+
 typedef struct NoriHipSceneDesc {
     uint32_t                n_nodes;   const NoriHipNode      *nodes;
     uint32_t                n_prims;   const NoriHipPrim      *prims;
@@ -144,6 +160,7 @@ typedef struct NoriHipSceneDesc {
     NoriHipCamera           camera;
     uint32_t                n_textures; const NoriHipTexture  *textures;      /* may be 0 / NULL */
     uint64_t                n_tex_bytes; const uint8_t        *tex_data;
+    NoriHipEnvMap           env;                                               /* env.texture = 0: none */
 } NoriHipSceneDesc;
 
 /* ray in, 32 B: replaces Ray3f (include/nori/ray.h:38-100); dRcp is recomputed on the device */
