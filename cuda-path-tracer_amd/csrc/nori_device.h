@@ -297,9 +297,19 @@ template <bool ANY> struct Trav {
         if (n > 1) stk.push(sp++, make_uint2(ref[1], __float_as_uint(nr[1])));
         cur = n ? ref[0] : ND_POP; cur_near = n ? nr[0] : cur_near;
     }
+    // the same when no lane of the wave wants its children by distance: slot order is visiting order, nothing to sort
+    template <typename StackT> __device__ __forceinline__ void box4_finish_inorder(const float nr[4], const bool hit[4], const uint32_t ref[4], StackT &stk) {
+        if (hit[3] & (hit[0] | hit[1] | hit[2])) stk.push(sp++, make_uint2(ref[3], __float_as_uint(nr[3])));
+        if (hit[2] & (hit[0] | hit[1])) stk.push(sp++, make_uint2(ref[2], __float_as_uint(nr[2])));
+        if (hit[1] & hit[0]) stk.push(sp++, make_uint2(ref[1], __float_as_uint(nr[1])));
+        const bool any_hit = hit[0] | hit[1] | hit[2] | hit[3];
+        cur = hit[0] ? ref[0] : hit[1] ? ref[1] : hit[2] ? ref[2] : hit[3] ? ref[3] : ND_POP;
+        cur_near = hit[0] ? nr[0] : hit[1] ? nr[1] : hit[2] ? nr[2] : any_hit ? nr[3] : cur_near;
+    }
     // direction components all normal numbers: min/max form, as box_compute_fast
     // (both forms return the number of boxes the node holds, for the statistics)
-    template <typename StackT> __device__ __forceinline__ uint32_t box_step4_fast(const float4 *nodes4, StackT &stk, const bool ordered) {
+    // `sort` (wave-uniform): false when no lane of the wave is `ordered`
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step4_fast(const float4 *nodes4, StackT &stk, const bool ordered, const bool sort = true) {
         const float4 *q = nodes4 + 8 * (size_t) cur;
         const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5]; const float4 cr = q[6];
         const float lx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ly[4] = {mny.x, mny.y, mny.z, mny.w}, lz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
@@ -316,7 +326,7 @@ template <bool ANY> struct Trav {
             nr[k] = nn; hit[k] = (nn <= ff) & (mint <= ff) & (nn <= maxt) & (ref[k] != NORI_HIP_NO_CHILD);
         }
         const uint32_t n_valid = (uint32_t) (ref[0] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[1] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[2] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[3] != NORI_HIP_NO_CHILD);
-        box4_finish(nr, hit, ref, stk, ordered);
+        if (sort) box4_finish(nr, hit, ref, stk, ordered); else box4_finish_inorder(nr, hit, ref, stk);
         return n_valid;
     }
     // any ray: the reference's test as written (zero, denormal or NaN direction components)

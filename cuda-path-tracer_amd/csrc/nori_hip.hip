@@ -776,7 +776,8 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
             // the reference's order unless sc.ordered
             const bool ord = (((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 2)) || (sc.ordered & 1);
             if (WIDE) {
-                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord); }
+                const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
+                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort); }
                 else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
             } else {
                 n_boxes += 2u * (unsigned int) __popcll(m_in);
@@ -808,7 +809,8 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
                 if (PROF) { pf[1]++; pf[2] += __popcll(m_in2); }
                 const bool ord = (((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 2)) || (sc.ordered & 1);
                 if (WIDE) {
-                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord); }
+                    const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
+                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort); }
                     else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
                 } else {
                     n_boxes += 2u * (unsigned int) __popcll(m_in2);

@@ -7,7 +7,7 @@
 //   k_hierarchy one thread per inner node: its range of sorted records and split (Karras 2012, "Maximizing
 //               parallelism in the construction of BVHs, octrees and k-d trees"); equal codes are told apart by
 //               their position, so keys are unique
-//   k_refit     one thread per leaf walks to the root; the second thread to arrive at a node computes its box
+//   k_refit_pass  bottom-up in passes: a node whose children are finished takes the union of their boxes
 //   k_depth     depth of every leaf -> depth of the tree (the traversal stack holds ND_STACK entries)
 //   k_reorder   records into sorted (leaf) order
 //   k_emit      one thread per inner node: the 64-byte node with both children's boxes; subtrees of at most
@@ -126,39 +126,30 @@ __global__ __launch_bounds__(256) void k_hierarchy(int n, const unsigned long lo
     if (i == 0) parent_inner[0] = 0xffffffffu;
 }
 
-// node boxes cross from the thread that wrote them to the thread that arrives second at the parent, possibly on
-// another XCD: device-scope atomic stores / loads, ordered by fences around the arrival counter
-__device__ __forceinline__ void st_dev(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_dev(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-__global__ __launch_bounds__(256) void k_refit(uint32_t n, const uint32_t *vals, const float4 *pmin, const float4 *pmax, const uint32_t *left, const uint32_t *right,
-                                               const uint32_t *parent_inner, const uint32_t *parent_leaf, float *nbox /* 8 floats per inner node: min xyz _, max xyz _ */,
-                                               uint32_t *arrived) {
+// Boxes of the inner nodes, bottom-up in passes: in pass p a node whose children were both finished in earlier passes takes the
+// union of their boxes and records p in `done`.  A child finished in the same pass still reads as unfinished (its mark is p, not
+// below p), and what a pass reads of the passes before it is ordered by the kernel boundary, so plain loads and stores do.  The tree
+// is `depth` levels high, so `depth` passes finish it.  (One thread per leaf walking up with an arrival counter per node - the usual
+// form - needs device-scope 4-byte stores and fences at every step; on ten million records that took 56 ms.)
+__global__ __launch_bounds__(256) void k_refit_pass(uint32_t n_inner, uint32_t pass, const uint32_t *vals, const float4 *pmin, const float4 *pmax, const uint32_t *left, const uint32_t *right,
+                                                    float *nbox /* 8 floats per inner node: min xyz _, max xyz _ */, uint32_t *done) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t cur = parent_leaf[i];
-    for (;;) {
-        __threadfence();
-        if (atomicAdd(&arrived[cur], 1u) == 0u) return;                   // the sibling subtree is not finished: its thread goes on
-        __threadfence();
-        float mn[3], mx[3];
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t c = side ? right[cur] : left[cur];
-            float cmn[3], cmx[3];
-            if (c & LB_LEAF) {
-                const float4 a = pmin[vals[c & 0x7fffffffu]], b = pmax[vals[c & 0x7fffffffu]];
-                cmn[0] = a.x; cmn[1] = a.y; cmn[2] = a.z; cmx[0] = b.x; cmx[1] = b.y; cmx[2] = b.z;
-            } else {
-                const float *q = nbox + 8 * (size_t) c;
-                for (int a = 0; a < 3; ++a) { cmn[a] = ld_dev(q + a); cmx[a] = ld_dev(q + 4 + a); }
-            }
-            for (int a = 0; a < 3; ++a) { mn[a] = side ? fminf(mn[a], cmn[a]) : cmn[a]; mx[a] = side ? fmaxf(mx[a], cmx[a]) : cmx[a]; }
-        }
-        float *q = nbox + 8 * (size_t) cur;
-        for (int a = 0; a < 3; ++a) { st_dev(q + a, mn[a]); st_dev(q + 4 + a, mx[a]); }
-        if (cur == 0u) return;
-        cur = parent_inner[cur];
+    if (i >= n_inner || done[i]) return;
+    const uint32_t l = left[i], r = right[i];
+    if (!(l & LB_LEAF)) { const uint32_t d = done[l]; if (d == 0u || d >= pass) return; }
+    if (!(r & LB_LEAF)) { const uint32_t d = done[r]; if (d == 0u || d >= pass) return; }
+    float mn[3], mx[3];
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t c = side ? r : l;
+        float4 a, b;
+        if (c & LB_LEAF) { a = pmin[vals[c & 0x7fffffffu]]; b = pmax[vals[c & 0x7fffffffu]]; }
+        else { const float4 *q = reinterpret_cast<const float4 *>(nbox + 8 * (size_t) c); a = q[0]; b = q[1]; }
+        const float cmn[3] = {a.x, a.y, a.z}, cmx[3] = {b.x, b.y, b.z};
+        for (int k = 0; k < 3; ++k) { mn[k] = side ? fminf(mn[k], cmn[k]) : cmn[k]; mx[k] = side ? fmaxf(mx[k], cmx[k]) : cmx[k]; }
     }
+    float4 *q = reinterpret_cast<float4 *>(nbox + 8 * (size_t) i);
+    q[0] = make_float4(mn[0], mn[1], mn[2], 0.f); q[1] = make_float4(mx[0], mx[1], mx[2], 0.f);
+    done[i] = pass;
 }
 
 __global__ __launch_bounds__(256) void k_depth(uint32_t n, const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t *max_depth) {
@@ -382,8 +373,9 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
         cleanup();
         return NORI_HIP_EINVAL;
     }
-    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals_s, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) left,
-                       (const uint32_t *) right, (const uint32_t *) parent_inner, (const uint32_t *) parent_leaf, nbox, arrived);
+    for (uint32_t pass = 1; pass <= res.depth + 1u; ++pass)
+        hipLaunchKernelGGL(k_refit_pass, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, pass, (const uint32_t *) vals_s, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) left,
+                           (const uint32_t *) right, nbox, arrived);
     LCHK(hipGetLastError());
     hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals_s, prims_in, shade_in, prims_out, shade_out);
     LCHK(hipGetLastError());
