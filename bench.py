@@ -272,7 +272,12 @@ def main():
     rays = rays_rank / args.steps                                              # this rank, per step
     # algorithmic bytes: 32 B per box tested + 40 B per primitive record tested + 44 B ray in + 16 B hit out per ray
     if wavefront:
-        alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays              # per trace launch
+        if st["extend_width"] == 8:
+            # quantised eight-box nodes: a visit reads one 128-byte node whatever the number of children in use (a box is 6 bytes
+            # there, not the reference's 32: counting 32 B per box tested would credit the kernel with bytes nobody needs)
+            alg_bytes = 128.0 * st["extend_visits"] / launches + 40.0 * k_prims + 60.0 * k_rays
+        else:
+            alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays          # per trace launch
         kname = ctx.trace_kernel_name()
     else:
         alg_bytes = (32.0 * st["boxes_tested"] + 40.0 * st["prims_tested"]) / args.steps + 60.0 * rays + 32.0 * samples_per_step
@@ -309,7 +314,8 @@ def main():
                      "valu_issue_busy": issue,
                      "note": roof_note,
                      "kernel_ms": round(kernel_ms, 4), "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "boxes_tested_per_ray": round(st["boxes_tested"] / max(1.0, rays_rank), 2), "prims_tested_per_ray": round(st["prims_tested"] / max(1.0, rays_rank), 2)},
+                     "boxes_tested_per_ray": round(st["boxes_tested"] / max(1.0, rays_rank), 2), "prims_tested_per_ray": round(st["prims_tested"] / max(1.0, rays_rank), 2),
+                     "node_width": int(st["extend_width"]), "node_visits_per_ray": (round(st["extend_visits"] / max(1.0, st["extend_rays"]), 2) if wavefront else None)},
     }
     if secondary:
         out["secondary"] = secondary

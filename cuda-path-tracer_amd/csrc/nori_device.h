@@ -94,6 +94,8 @@ struct DevScene {
     const uint8_t *tex_data;
     const float4 *nodes4;              // the same tree as 128-byte four-box nodes (8 x float4 per node, see Trav::box_step4), or null
     uint32_t root4;                    // child reference of the root in nodes4 numbering
+    const uint4 *nodes8;               // device-built trees beyond the caches: the tree as 128-byte eight-box nodes with quantised boxes (Trav::box_step8;
+                                       // root = node 0), or null.  When set, every traversal of a render and nori_hip_trace walk these.
     uint32_t root, n_emitters;
     int ordered;                       // bit 0 clear: the reference's child order (left first; decides ties, bit-exact hits).  set: nearer child first —
                                        // fewer box tests, same hit except where two primitives tie within rounding (NORI_HIP_ORDER=near)
@@ -165,6 +167,7 @@ struct CachedNodes {
 #ifndef ND_STACK
 #define ND_STACK 64        /* the reference's traversal stack holds 64 entries (src/bvh.cpp:405) */
 #endif
+#define ND_STACK8 96       /* eight-box nodes leave up to seven entries per level; the build reports what a tree needs (lbvh::Result::stack8) */
 
 // BVH::rayIntersect (src/bvh.cpp:404-463) over 64-byte two-box nodes, in the reference's visiting order
 // (left subtree first, right pushed), so closest-hit ties resolve to the same primitive.
@@ -347,6 +350,82 @@ template <bool ANY> struct Trav {
         box4_finish(nr, hit, ref, stk, ordered);
         return n_valid;
     }
+    // ---- eight-box nodes with quantised boxes (device-built trees that do not fit the caches; layout: lbvh::k_wide_emit8) -----------
+    // A child's box is p + q * unit per axis with 8-bit q, low corners rounded down and high corners up, so it contains the box of
+    // the binary tree: a ray reaches every record it reached before (and a few boxes more), closest hits are the same primitive
+    // except on ties in t, any-hit answers the same.  The slab distances are t = q * (unit * rcp) + (p - o) * rcp: two products per
+    // axis and node, then one multiply-add per plane; which plane is the near one follows from the sign of the direction.  The
+    // children that pass are visited nearest first: each finds its rank among the others by comparisons (no sorting network: the
+    // rank is the stack position, the payload never moves), the nearest becomes `cur`, the rest go on the stack far to near.
+    // Entry distances are clamped to mint from below (the pop test `entry <= maxt` is unchanged by that).
+    // Returns the number of children in use (statistics).
+#define ND_Q8(W, K) ((float) (((W) >> (8 * (K))) & 0xffu))
+    template <typename StackT> __device__ __forceinline__ void box8_finish(const float nr[8], const bool hit[8], const uint32_t ref[8], StackT &stk) {
+        float key[8]; int rank[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { key[k] = hit[k] ? nr[k] : ND_INF; rank[k] = 0; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = j + 1; k < 8; ++k) { const bool c = key[j] <= key[k]; rank[k] += c ? 1 : 0; rank[j] += c ? 0 : 1; }
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) n += hit[k] ? 1 : 0;
+        uint32_t c0 = ND_POP; float n0 = cur_near;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (hit[k] && rank[k] > 0) stk.push(sp + (n - 1 - rank[k]), make_uint2(ref[k], __float_as_uint(nr[k])));
+            const bool first = hit[k] && rank[k] == 0;
+            c0 = first ? ref[k] : c0; n0 = first ? nr[k] : n0;
+        }
+        sp += n > 1 ? n - 1 : 0;
+        cur = c0; cur_near = n0;
+    }
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step8_fast(const uint4 *nodes8, StackT &stk) {
+        const uint4 *q = nodes8 + 8 * (size_t) cur;
+        const uint4 h = q[0], qa = q[1], qb = q[2], qc = q[3], r0 = q[4], r1 = q[5];
+        const float ux = __uint_as_float((h.w & 0xffu) << 23), uy = __uint_as_float(((h.w >> 8) & 0xffu) << 23), uz = __uint_as_float(((h.w >> 16) & 0xffu) << 23);
+        const float ax = ux * rcp.x, ay = uy * rcp.y, az = uz * rcp.z;
+        const float bx = (__uint_as_float(h.x) - o.x) * rcp.x, by = (__uint_as_float(h.y) - o.y) * rcp.y, bz = (__uint_as_float(h.z) - o.z) * rcp.z;
+        // near and far planes per axis: the low corner is the near one when the direction is positive
+        const bool sx = rcp.x < 0.f, sy = rcp.y < 0.f, sz = rcp.z < 0.f;
+        const uint32_t nx[2] = {sx ? qb.z : qa.x, sx ? qb.w : qa.y}, fx[2] = {sx ? qa.x : qb.z, sx ? qa.y : qb.w};
+        const uint32_t ny[2] = {sy ? qc.x : qa.z, sy ? qc.y : qa.w}, fy[2] = {sy ? qa.z : qc.x, sy ? qa.w : qc.y};
+        const uint32_t nz[2] = {sz ? qc.z : qb.x, sz ? qc.w : qb.y}, fz[2] = {sz ? qb.x : qc.z, sz ? qb.y : qc.w};
+        const uint32_t ref[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float nr[8]; bool hit[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float tnx = __builtin_fmaf(ND_Q8(nx[k >> 2], k & 3), ax, bx), tfx = __builtin_fmaf(ND_Q8(fx[k >> 2], k & 3), ax, bx);
+            const float tny = __builtin_fmaf(ND_Q8(ny[k >> 2], k & 3), ay, by), tfy = __builtin_fmaf(ND_Q8(fy[k >> 2], k & 3), ay, by);
+            const float tnz = __builtin_fmaf(ND_Q8(nz[k >> 2], k & 3), az, bz), tfz = __builtin_fmaf(ND_Q8(fz[k >> 2], k & 3), az, bz);
+            const float nn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, mint));
+            const float ff = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, maxt));
+            nr[k] = nn; hit[k] = (nn <= ff) & (ref[k] != NORI_HIP_NO_CHILD);
+        }
+        box8_finish(nr, hit, ref, stk);
+        return h.w >> 24;
+    }
+    // any ray (a zero, denormal or NaN direction component): the boxes decoded, then the reference's test as written
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step8(const uint4 *nodes8, StackT &stk) {
+        const uint4 *q = nodes8 + 8 * (size_t) cur;
+        const uint4 h = q[0], qa = q[1], qb = q[2], qc = q[3], r0 = q[4], r1 = q[5];
+        const float u[3] = {__uint_as_float((h.w & 0xffu) << 23), __uint_as_float(((h.w >> 8) & 0xffu) << 23), __uint_as_float(((h.w >> 16) & 0xffu) << 23)};
+        const float p[3] = {__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z)};
+        const uint32_t lo[3][2] = {{qa.x, qa.y}, {qa.z, qa.w}, {qb.x, qb.y}}, hi[3][2] = {{qb.z, qb.w}, {qc.x, qc.y}, {qc.z, qc.w}};
+        const uint32_t ref[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        float nr[8]; bool hit[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float bmin[3], bmax[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { bmin[a] = p[a] + ND_Q8(lo[a][k >> 2], k & 3) * u[a]; bmax[a] = p[a] + ND_Q8(hi[a][k >> 2], k & 3) * u[a]; }
+            float nn; const bool hh = slab(bmin, bmax, o, d, rcp, mint, maxt, nn);
+            nr[k] = nn < mint ? mint : nn; hit[k] = hh & (ref[k] != NORI_HIP_NO_CHILD);
+        }
+        box8_finish(nr, hit, ref, stk);
+        return h.w >> 24;
+    }
     // one record of the current leaf; afterwards the lane is at the next record, in ND_POP (leaf finished) or done
     __device__ __forceinline__ void prim_step(const DevScene &sc, uint32_t &n_prims) { prim_step(sc, n_prims, ANY); }
     // `any`: stop at the first hit (a per-lane flag where one kernel traces shadow and extend rays together)
@@ -471,12 +550,33 @@ __device__ __forceinline__ bool trace4(const DevScene &sc, const Ray &ray_in, Hi
     return tv.found;
 }
 
+// the same loop over the quantised eight-box nodes (sc.nodes8 must not be null; the stack must hold ND_STACK8 entries)
+template <bool ANY, typename StackT>
+__device__ __forceinline__ bool trace8(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
+    Trav<ANY> tv;
+    if (tv.begin(sc, ray_in, n_nodes)) tv.cur = sc.root4;
+    for (;;) {
+        const unsigned long long m_in = __ballot(tv.at_inner());
+        if (m_in) {
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step8_fast(sc.nodes8, stk); }
+            else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step8(sc.nodes8, stk); else n_nodes += tv.box_step8_fast(sc.nodes8, stk); }
+        }
+        const unsigned long long m_lf = __ballot(tv.at_leaf());
+        if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) { if (tv.at_leaf()) tv.prim_step(sc, n_prims); }
+        if (tv.at_pop()) tv.pop_step(stk);
+        if (__ballot(!tv.done()) == 0ull) break;
+    }
+    hit = tv.hit;
+    return tv.found;
+}
+
 // per-lane stack in private (scratch) memory
-struct ScratchStack {
-    uint2 e[ND_STACK];
+template <int SIZE> struct ScratchStackT {
+    uint2 e[SIZE];
     __device__ __forceinline__ void push(int i, uint2 v) { e[i] = v; }
     __device__ __forceinline__ uint2 pop(int i) const { return e[i]; }
 };
+typedef ScratchStackT<ND_STACK> ScratchStack;
 
 // Per-lane traversal stack with its first LDS_DEPTH entries in LDS ([entry][lane] layout: the 64 lanes of a wave
 // touch 64 consecutive 8-byte words, conflict-free for ds_read/write_b64) and the rare deeper entries in scratch.

@@ -51,7 +51,7 @@ struct DevBufs {
 // Every counter the kernels bump therefore sits on a line of its own, and the hot ones are striped over ND_STRIPES
 // lines that the reader sums.
 #define ND_STRIPES 32
-struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims, ext_rays, ext_nodes, ext_prims; unsigned long long prof[2][10]; };
+struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims, ext_rays, ext_nodes, ext_prims, ext_visits; unsigned long long prof[2][10]; };
 __device__ __forceinline__ DevStats *my_stats(DevStats *stats) { return stats + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ND_STRIPES - 1)); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -61,14 +61,14 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *ra
     const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
     float4 a = rp[0], b = rp[1];
     Ray ray; ray.o = f3(a.x, a.y, a.z); ray.mint = a.w; ray.d = f3(b.x, b.y, b.z); ray.maxt = b.w;
-    ScratchStack stk; Hit hit; uint32_t nn = 0, np = 0;
+    ScratchStackT<ND_STACK8> stk; Hit hit; uint32_t nn = 0, np = 0;
     NoriHipHit out; out.prim = NORI_HIP_MISS; out.t = 0.f; out.u = 0.f; out.v = 0.f;
     if (any_hit) {
-        if (trace<true>(sc, ray, hit, stk, nn, np)) out.prim = 1u;
+        if (sc.nodes8 ? trace8<true>(sc, ray, hit, stk, nn, np) : trace<true>(sc, ray, hit, stk, nn, np)) out.prim = 1u;
         hits[i] = out;
         return;
     }
-    bool found = trace<false>(sc, ray, hit, stk, nn, np);
+    bool found = sc.nodes8 ? trace8<false>(sc, ray, hit, stk, nn, np) : trace<false>(sc, ray, hit, stk, nn, np);
     if (found) {
         Surface sf; surface_from_hit<true>(sc, ray, hit, sf, true);
         out.prim = sf.prim; out.t = hit.t; out.u = sf.uv.x; out.v = sf.uv.y;
@@ -636,14 +636,17 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // HBM line and a ray's chain of dependent fetches is about half as long; up to three stack entries per visit, so the LDS part of
 // the stack is deeper (TRACE_DEPTH_W).
 #define TRACE_DEPTH_W 8
+#ifndef TRACE_DEPTH_W8
+#define TRACE_DEPTH_W8 8     /* ... of the eight-box trace stage (up to seven entries per visit) */
+#endif
 #ifndef ND_WIDE_WAVES
 #define ND_WIDE_WAVES 5         /* waves per SIMD the four-box trace stage is built for */
 #endif
 // MASKED (scenes with subsurface shapes): an extend ray whose slot holds ND_PROBE_MARK is a probe, a closest-hit query restricted
 // to the records of one shape (BVH::rayIntersect's mask, src/bvh.cpp:438).
-template <int KIND, bool PROF, bool SPEC, bool WIDE, bool MASKED = false>
+template <int KIND, bool PROF, bool SPEC, int WIDE, bool MASKED = false>
 __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
-    constexpr int DEPTH = WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
+    constexpr int DEPTH = WIDE == 8 ? TRACE_DEPTH_W8 : WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
     extern __shared__ float4 dyn_lds[];
     const unsigned int nw = blockDim.x >> 6;
@@ -654,8 +657,20 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
     unsigned int *const st_slot = st_slot_all + (threadIdx.x >> 6) * 64;
     const unsigned int lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     constexpr bool ANY = (KIND == TK_SHADOW);
-    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, nb_pool = (n_slots + 63u) >> 6, n_batches = (KIND == TK_BOTH) ? 2u * nb_pool : nb_pool;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, nb_pool = (n_slots + 63u) >> 6;
+    unsigned int n_batches = (KIND == TK_BOTH) ? 2u * nb_pool : nb_pool;
     unsigned int b_next = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform: next batch of the static share
+    // XCD-aware deal (sorted rays only).  Workgroups b and b + 8 share an XCD and its 4 MiB L2 (observed placement, used for speed
+    // only: any placement gives the same results).  dealt round-robin, the eight L2s would each see rays from the whole sorted range
+    // and hold eight copies of the same nodes and records.  Instead the sorted order is cut into 8 x_k chunks, chunk c belongs to
+    // the workgroups with b % 8 == c % 8, and those walk their chunks one after the other (a chunk's shadow batches, then its extend
+    // batches, whose rays start where the shadow rays end): an L2 then serves one region of the tree at a time.  A batch number b is
+    // a position in that deal: round b / n_waves of wave b % n_waves (static part), or entry d % per_q of queue d / per_q.
+    const unsigned int x_k = (box2_lanes >> 20) & 0xffu;
+    const bool xmap = KIND == TK_BOTH && order != nullptr && x_k != 0u && (gridDim.x & 7u) == 0u;
+    const unsigned int x_wx = n_waves >> 3, x_cb = xmap ? (nb_pool + 8u * x_k - 1u) / (8u * x_k) : 0u;       // waves per XCD, batches of one kind per chunk
+    const unsigned int x_w = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);                       // this wave among its XCD's
+    if (xmap) n_batches = ((2u * x_k * x_cb + x_wx - 1u) / x_wx) * n_waves;
     // The last dyn_pct percent of the rounds are not dealt statically: their batches [n_static, n_batches) sit in eight
     // queues (one cursor each, on its own cache line) and a wave that has finished its share takes from its queue, then
     // from the others, so that the waves end together.
@@ -670,9 +685,10 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
     float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), ld4 = make_float4(0.f, 0.f, 0.f, -1.f); unsigned int l_base = 0;
     unsigned int l_slot = 0;                                             // the slot of this lane's ray of the batch in flight
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
-    uint2 stack_spill[ND_STACK - DEPTH];
+    uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - DEPTH];
     LdsStackT<DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + wv * (DEPTH * 64) + lane;
-    unsigned int n_boxes_lane = 0;                                       // WIDE: boxes of the nodes this lane visited
+    unsigned int n_boxes_lane = 0;
+    unsigned int n_visits = 0;                                           // WIDE: node fetches of the wave (statistics; wave-uniform sum of ballots)                                       // WIDE: boxes of the nodes this lane visited
     // (an LDS copy of the top of the tree, CachedNodes, was measured here: no gain, and a branch per node visit)
     GlobalNodes nodes; nodes.nodes = sc.nodes;
     bool any = ANY;                                                      // this lane's ray is a shadow ray
@@ -730,8 +746,19 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
             }
         }
         if (b_take != 0xffffffffu) {
+            if (xmap) {
+                unsigned int x, j;
+                if (b_take < n_static) { x = blockIdx.x & 7u; j = (b_take / n_waves) * x_wx + x_w; }
+                else { const unsigned int d = b_take - n_static; x = d / per_q; j = (n_static / n_waves) * x_wx + (d - x * per_q); }
+                const unsigned int k = j / (2u * x_cb), within = j - k * 2u * x_cb;
+                l_any = within < x_cb;
+                const unsigned int pb = (x + 8u * k) * x_cb + (l_any ? within : within - x_cb);
+                if (k >= x_k || pb >= nb_pool) { l_any = false; l_base = nb_pool << 6; }      // a position past the end of the deal: an empty batch
+                else l_base = pb << 6;
+            } else {
             l_any = (KIND == TK_BOTH) ? (b_take < nb_pool) : ANY;
             l_base = ((KIND == TK_BOTH && !l_any) ? b_take - nb_pool : b_take) << 6;
+            }
             const unsigned int pos = l_base + lane;
             if (pos < n_slots) {
                 // (through the sorted order the slot number is one more dependent load; it is issued a batch ahead like the ray itself)
@@ -775,7 +802,12 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
             // shadow rays take the nearer child first (any child order gives the same any-hit answer), extend rays
             // the reference's order unless sc.ordered
             const bool ord = (((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 2)) || (sc.ordered & 1);
-            if (WIDE) {
+            if (WIDE == 8) {
+                n_visits += (unsigned int) __popcll(m_in);
+                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step8_fast(sc.nodes8, stk); }
+                else if (tv.at_inner()) n_boxes_lane += tv.box_step8(sc.nodes8, stk);
+            } else if (WIDE) {
+                n_visits += (unsigned int) __popcll(m_in);
                 const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
                 if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort); }
                 else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
@@ -808,7 +840,12 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
             if ((unsigned int) __popcll(m_in2) >= (box2_lanes & 0xffu)) {
                 if (PROF) { pf[1]++; pf[2] += __popcll(m_in2); }
                 const bool ord = (((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 2)) || (sc.ordered & 1);
-                if (WIDE) {
+                if (WIDE == 8) {
+                    n_visits += (unsigned int) __popcll(m_in2);
+                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step8_fast(sc.nodes8, stk); }
+                    else if (tv.at_inner()) n_boxes_lane += tv.box_step8(sc.nodes8, stk);
+                } else if (WIDE) {
+                    n_visits += (unsigned int) __popcll(m_in2);
                     const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
                     if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort); }
                     else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
@@ -844,30 +881,38 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
         atomicAdd(ANY ? &st->shadow : &st->closest, v[0]); atomicAdd(&st->nodes, v[1]); atomicAdd(&st->prims, v[2]);
         if (KIND == TK_BOTH) atomicAdd(&st->shadow, v[3]);
         // the work of the kernel the roofline is quoted on (the extend stage, or the merged trace stage)
-        if (!ANY) { atomicAdd(&st->ext_rays, v[0] + v[3]); atomicAdd(&st->ext_nodes, v[1]); atomicAdd(&st->ext_prims, v[2]); }
+        if (!ANY) { atomicAdd(&st->ext_rays, v[0] + v[3]); atomicAdd(&st->ext_nodes, v[1]); atomicAdd(&st->ext_prims, v[2]); if (WIDE) atomicAdd(&st->ext_visits, (unsigned long long) n_visits); }
         if (PROF) for (int k = 0; k < 10; ++k) atomicAdd(&st->prof[ANY ? 1 : 0][k], (unsigned long long) pf[k]);
     }
 }
 
 template <int KIND, bool PROF, bool SPEC = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void k_trace_pool(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt) {
-    trace_pool_body<KIND, PROF, SPEC, false>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, nullptr);
+    trace_pool_body<KIND, PROF, SPEC, 0>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, nullptr);
 }
 // ... for scenes with subsurface shapes (probe rays; no speculative traversal)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4_masked(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
-    trace_pool_body<TK_BOTH, false, false, true, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
+    trace_pool_body<TK_BOTH, false, false, 4, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
 }
 // the merged trace stage over four-box nodes
 template <bool PROF, bool SPEC>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
-    trace_pool_body<TK_BOTH, PROF, SPEC, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
+    trace_pool_body<TK_BOTH, PROF, SPEC, 4>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
+}
+// ... over quantised eight-box nodes (device-built trees that do not fit the caches)
+#ifndef ND_WIDE8_WAVES
+#define ND_WIDE8_WAVES 4
+#endif
+template <bool PROF, bool SPEC>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE8_WAVES))) void k_trace_pool8(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
+    trace_pool_body<TK_BOTH, PROF, SPEC, 8>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
 }
 
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
 // stage launch per bounce would be mostly launch latency.  Persistent waves run the surviving paths of the live
 // list to their end, one bounce per loop trip (shade -> shadow -> extend in registers); wave w of W takes the
 // 64-entry batches w, w+W, ... and a lane whose path has ended takes the next entry of the wave's batch.
-template <bool EXT, bool WIDE = false>
+template <bool EXT, int WIDE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
     __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
     const unsigned int n = CN_LIVE(cnt);
@@ -875,7 +920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, n_batches = (n + 63u) >> 6;
     unsigned int batch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
     unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
-    uint2 stack_spill[ND_STACK - LDS_DEPTH];
+    uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - LDS_DEPTH];
     LdsStack stk; stk.spill = stack_spill; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
     Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
     bool alive = false; unsigned int slot = 0;
@@ -937,11 +982,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             else shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
             if (so.has_shadow) {
                 Hit sh; ctr.shadow++;
-                if (!(WIDE ? trace4<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims))) ps.li = ps.li + so.contrib;
+                if (!(WIDE == 8 ? trace8<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : WIDE ? trace4<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims))) ps.li = ps.li + so.contrib;
             }
             bool go_on = !so.end;
             if (go_on) {
-                ctr.closest++; go_on = WIDE ? trace4<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims) : trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims);
+                ctr.closest++; go_on = WIDE == 8 ? trace8<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims) : WIDE ? trace4<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims) : trace<false>(sc, ps.ray, hit, stk, ctr.nodes, ctr.prims);
                 if (!go_on) ps.li = ps.li + env_miss<EXT>(sc, ps.ray.d, ps.t, ps.last_bsdf_pdf, ps.last_delta);
             }
             if (!go_on) {
@@ -1125,7 +1170,12 @@ struct NoriHipContext {
     DevScene sc;
     uint32_t n_prims = 0, n_nodes = 0;
     float4 *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;     // the tree as 128-byte four-box nodes (null: one-leaf tree, or too deep for the stack)
+    uint4 *d_nodes8 = nullptr; uint32_t n_nodes8 = 0;      // device-built trees beyond the caches: quantised eight-box nodes (null otherwise)
     bool wide = true;                 // NORI_HIP_WIDE=0: the trace stage walks the 64-byte two-box nodes
+    int wide8 = 0;                    // NORI_HIP_WIDE=8: device-built trees are walked through quantised eight-box nodes (measured on the 10 M-triangle workload:
+                                      // a third fewer node fetches, but 2.5 x the instructions per visit; slower than four-box nodes, so an option, not a default)
+    uint64_t trace_width = 0;         // boxes per node in the trace stage of the last render (NoriHipStats::extend_width)
+    size_t trace_lds_wide8 = 0;
     size_t trace_lds_wide = 0;
     NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
@@ -1173,6 +1223,7 @@ struct NoriHipContext {
     size_t trace_lds = 0;             // dynamic LDS of a trace-stage workgroup (set once, with the kernels' attribute, in nori_hip_create)
     int spec = -1;                    // NORI_HIP_SPEC: 1 / 0 = speculative traversal in the merged trace stage or not; -1 = unless the tree does not fit the
                                       // caches (there the stage waits for HBM lines, and the extra boxes that speculation lets pass cost more than the waiting it saves)
+    int xcd_chunks = -1;              // NORI_HIP_XCD: chunks of the sorted ray order per XCD in the trace stage's deal (0 = off, -1 = 64)
     int dyn_tries = 3;                // NORI_HIP_DYN_TRIES: queues a finishing wave tries (1..8)
     int dyn_pct = 15;                 // NORI_HIP_DYN: percent of the trace stage's rounds of batches that are handed out dynamically at the end
     int box2 = -1;                    // (-1 = 36, or 0 when the tree does not fit the caches) NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
@@ -1191,6 +1242,7 @@ struct NoriHipContext {
     }
     void free_scene() {
         hipFree(d_nodes4); d_nodes4 = nullptr; n_nodes4 = 0;
+        hipFree(d_nodes8); d_nodes8 = nullptr; n_nodes8 = 0;
         hipFree(d_env_cdf); d_env_cdf = nullptr;
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         hipFree(d_textures); hipFree(d_tex_data); d_textures = nullptr; d_tex_data = nullptr; ext = false;
@@ -1247,9 +1299,10 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_LBVH_MORTON")) c->lbvh_plain = std::string(e) == "plain";
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
-    if (const char *e = getenv("NORI_HIP_WIDE")) c->wide = atoi(e) != 0;
+    if (const char *e = getenv("NORI_HIP_WIDE")) { const int v = atoi(e); c->wide = v != 0; c->wide8 = v == 8 ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
+    if (const char *e = getenv("NORI_HIP_XCD")) { int v = atoi(e); if (v >= 0 && v <= 255) c->xcd_chunks = v; }
     if (const char *e = getenv("NORI_HIP_DYN")) { int v = atoi(e); if (v >= 0 && v <= 90) c->dyn_pct = v; }
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
     if (const char *e = getenv("NORI_HIP_COMPACT")) c->compact = atoi(e) != 0;
@@ -1291,6 +1344,11 @@ static int create_impl(NoriHipContext *c, int device) {
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
+    c->trace_lds_wide8 = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH_W8 * 64 * 8 + 64 * 52);
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide8));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide8));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide8));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool8<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide8));
     return NORI_HIP_OK;
 }
 
@@ -1443,12 +1501,19 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         hipError_t e3_ = hipMalloc((void **) &ctx->d_nodes, (size_t) std::max<uint32_t>(d->n_prims - 1, 1u) * sizeof(NoriHipNode));
         std::string lerr;
         rc = (e1_ != hipSuccess || e2_ != hipSuccess || e3_ != hipSuccess) ? NORI_HIP_EDEVICE
-             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf ? ctx->lbvh_leaf : (d->n_prims >= 1000000u ? 2u : 3u), ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->lbvh, lerr);
+             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf ? ctx->lbvh_leaf : (d->n_prims >= 1000000u ? 2u : 3u), ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->wide && ctx->wide8 == 1 && !ext, ctx->lbvh, lerr);
         hipFree(tmp_prims); hipFree(tmp_shade);
-        if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
+        if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; hipFree(ctx->lbvh.nodes8); ctx->lbvh.nodes8 = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
         ctx->d_nodes4 = (float4 *) ctx->lbvh.nodes4; ctx->n_nodes4 = ctx->lbvh.n_nodes4; ctx->lbvh.nodes4 = nullptr;
         // up to three stack entries per four-box level: deeper trees are walked through their two-box nodes
         if (3u * ctx->lbvh.depth4 > (uint32_t) (ND_STACK - 2)) { hipFree(ctx->d_nodes4); ctx->d_nodes4 = nullptr; ctx->n_nodes4 = 0; }
+        // quantised eight-box nodes (NORI_HIP_WIDE=8), if their traversal fits the stack; scenes with images or subsurface shapes
+        // keep the four-box walk (their kernels trace masked probe rays)
+        ctx->d_nodes8 = (uint4 *) ctx->lbvh.nodes8; ctx->n_nodes8 = ctx->lbvh.n_nodes8; ctx->lbvh.nodes8 = nullptr;
+        {
+            const bool use8 = ctx->d_nodes8 && ctx->d_nodes4 && ctx->lbvh.stack8 + 2u <= (uint32_t) ND_STACK8 && ctx->wide8 == 1;
+            if (!use8) { hipFree(ctx->d_nodes8); ctx->d_nodes8 = nullptr; ctx->n_nodes8 = 0; }
+        }
         root = ctx->lbvh.root;
         for (int i = 0; i < 3; ++i) { root_min[i] = ctx->lbvh.root_min[i]; root_max[i] = ctx->lbvh.root_max[i]; }
     } else {
@@ -1498,7 +1563,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
     sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
     // a device-built tree has no reference child order to keep: the nearer child is entered first
-    sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u;
+    sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u; sc.nodes8 = ctx->d_nodes8;
     sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = ((ctx->ordered || device_build) ? 1 : 0) | (ctx->any_near ? 2 : 0);
     for (int i = 0; i < 3; ++i) { sc.root_min[i] = root_min[i]; sc.root_max[i] = root_max[i]; }
     sc.cam = d->camera;
@@ -1715,6 +1780,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         job.tiles = reinterpret_cast<const int4 *>(ctx->d_tiles); job.patch_first = reinterpret_cast<const unsigned int *>(ctx->d_tiles + 4 * ND_MAX_TILES);
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
+    ctx->trace_width = 0;
     const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS, direct = ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS;
     // Scenes with images or subsurface shapes: the stages when the scene has subsurface shapes (their probe rays go through the trace
     // stage) and a tree with inner nodes, else the single kernel (image lookups on a few dozen primitives: measured faster).
@@ -1747,7 +1813,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     // issuing, and a few defaults change with that (measured on the 10 M-triangle workload): rays are ordered before every trace
     // launch, no speculative traversal, no second box step per trip, and half instead of a quarter of the call's paths in the pool
     // (fewer, larger launches: the stage's ramp-up and drain are paid less often).
-    const size_t tree_bytes = (size_t) (ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
+    const size_t tree_bytes = (size_t) (ctx->n_nodes8 ? (size_t) ctx->n_nodes8 * 128 : ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
     const bool big_tree = tree_bytes > ((size_t) 192 << 20);
     const unsigned int pool_cap = ctx->pool_slots ? ctx->pool_slots : (1u << 23);
     unsigned int P = pool_cap;
@@ -1785,14 +1851,17 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const bool wide = ctx->wide && ctx->d_nodes4 != nullptr && ctx->merge_trace;          // the merged trace stage over four-box nodes
     // the scene's tree and records against the 256 MiB of Infinity Cache: beyond that, ordering the rays pays for its sort
     const bool sort_rays = ctx->sort_rays < 0 ? big_tree : ctx->sort_rays != 0;
-    const int trace_waves = wide ? ND_WIDE_WAVES : 6;                                     // waves per SIMD the kernel is built for
-    const size_t trace_fixed = wide ? ctx->trace_lds_wide : ctx->trace_lds;               // stacks + staged rays (origin, direction, reciprocal direction, slot)
+    const bool wide8 = wide && ctx->d_nodes8 != nullptr && !ctx->has_ss;                  // ... over quantised eight-box nodes
+    ctx->trace_width = wide8 ? 8 : wide ? 4 : 2;
+    const int trace_waves = wide8 ? ND_WIDE8_WAVES : wide ? ND_WIDE_WAVES : 6;            // waves per SIMD the kernel is built for
+    const size_t trace_fixed = wide8 ? ctx->trace_lds_wide8 : wide ? ctx->trace_lds_wide : ctx->trace_lds;               // stacks + staged rays (origin, direction, reciprocal direction, slot)
     int trace_bpc = ctx->trace_blocks_per_cu;
     if (trace_bpc == 0) trace_bpc = std::max(1, std::min<int>((int) (trace_waves * 4 / trace_nw), (int) (163840 / trace_fixed)));
     const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (trace_waves * 4 / trace_nw)));     // more workgroups than that run in rounds
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
-    const unsigned int trace_box2 = (unsigned int) (ctx->box2 >= 0 ? ctx->box2 : (big_tree ? 0 : 36)) | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16);
+    const unsigned int xcd_chunks = (unsigned int) (ctx->xcd_chunks >= 0 ? ctx->xcd_chunks : 64);             // sorted rays: chunks of the sorted order per XCD (0: plain round-robin deal)
+    const unsigned int trace_box2 = (unsigned int) (ctx->box2 >= 0 ? ctx->box2 : (big_tree ? 0 : 36)) | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16) | (xcd_chunks << 20);
     const bool spec = ctx->spec >= 0 ? ctx->spec != 0 : !big_tree;
     const size_t trace_lds = trace_fixed;
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
@@ -1800,6 +1869,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     auto shade_run = [](unsigned int slots, unsigned int blocks) { return (((slots + blocks - 1) / blocks) + 255u) & ~255u; };   // = per_block in shade_body
     auto size_grids = [&](unsigned int slots) {
         trace_blocks = std::max(1u, std::min<unsigned>((slots + trace_threads - 1) / trace_threads, (unsigned) ctx->n_cus * (unsigned) trace_bpc));
+        if (sort_rays && trace_blocks > 8u) trace_blocks &= ~7u;             // the XCD-aware deal of sorted rays wants the same number of workgroups on every XCD
         shade_blocks = std::max(1u, std::min<unsigned>((slots + 255) / 256, (unsigned) ctx->n_cus * (unsigned) ctx->shade_blocks_per_cu));
         if (shade_run(slots, shade_blocks) > SHADE_RUN_MAX) shade_blocks = (slots + (SHADE_RUN_MAX - 256u) - 1) / (SHADE_RUN_MAX - 256u);   // 16-bit offsets in the run lists
         shade_lds = (size_t) shade_run(slots, shade_blocks) * sizeof(unsigned short);
@@ -1833,6 +1903,10 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
                 HIPCHK(hipEventRecord(ctx->ext_ev[ctx->ext_used], ctx->stream));
                 if (wide && ctx->has_ss) {
                     hipLaunchKernelGGL(k_trace_pool4_masked, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
+                } else if (wide8) {
+                    void (*k8)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *, const unsigned int *) =
+                        ctx->profile ? (spec ? k_trace_pool8<true, true> : k_trace_pool8<true, false>) : (spec ? k_trace_pool8<false, true> : k_trace_pool8<false, false>);
+                    hipLaunchKernelGGL(k8, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
                 } else if (wide) {
                     void (*k4)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *, const unsigned int *) =
                         ctx->profile ? (spec ? k_trace_pool4<true, true> : k_trace_pool4<true, false>) : (spec ? k_trace_pool4<false, true> : k_trace_pool4<false, false>);
@@ -1863,9 +1937,10 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
                 const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u)));
-                if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, true>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (wide) hipLaunchKernelGGL((k_finish<false, true>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (wide8) hipLaunchKernelGGL((k_finish<false, 8>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (wide) hipLaunchKernelGGL((k_finish<false, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
                 ++it;
@@ -1991,7 +2066,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     HIPCHK(hipMemcpy(stripes.data(), ctx->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
     DevStats ds; std::memset(&ds, 0, sizeof(ds));
     for (const DevStats &t : stripes) {
-        ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims;
+        ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims; ds.ext_visits += t.ext_visits;
         ds.samples += t.samples; ds.closest += t.closest; ds.shadow += t.shadow; ds.invalid += t.invalid; ds.nodes += t.nodes; ds.prims += t.prims;
         for (int k = 0; k < 2; ++k) for (int j = 0; j < 10; ++j) ds.prof[k][j] += t.prof[k][j];
     }
@@ -2002,6 +2077,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     ctx->fold_ext_events();
     ctx->stats.extend_ms = ctx->ext_ms_acc; ctx->stats.extend_launches = ctx->ext_launches;
     ctx->stats.extend_rays = ds.ext_rays; ctx->stats.extend_boxes = ds.ext_nodes; ctx->stats.extend_prims = ds.ext_prims;
+    ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width;
     if (ctx->profile) {
         static const char *names[10] = {"trips", "box_runs", "box_lanes", "prim_runs", "prim_lanes", "pop_runs", "pop_lanes", "refill_runs", "retired", "busy_lanes"};
         for (int k = 0; k < 2; ++k) {

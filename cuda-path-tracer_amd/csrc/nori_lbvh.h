@@ -19,6 +19,10 @@ struct Result {
     void *nodes4 = nullptr;        // the same tree as 128-byte four-box nodes (Trav::box_step4), hipMalloc'ed here, owned by the caller;
     uint32_t n_nodes4 = 0;         // null when the tree is one leaf.  Its root is node 0.
     uint32_t depth4 = 0;           // levels of four-box nodes (a traversal pushes at most three entries per level)
+    void *nodes8 = nullptr;        // (want8) the same tree as 128-byte eight-box nodes with quantised boxes (Trav::box_step8), hipMalloc'ed here,
+    uint32_t n_nodes8 = 0;         // owned by the caller; root = node 0
+    uint32_t depth8 = 0;           // levels of eight-box nodes
+    uint32_t stack8 = 0;           // most stack entries a traversal of the eight-box nodes can hold at once
 };
 
 // prims_in / shade_in: n records in any order (bit 31 of shape_flags ignored).  prims_out / shade_out: n records in
@@ -26,9 +30,10 @@ struct Result {
 // longer than `big` times the scene on some axis go into a subtree of their own under the root (0: off).
 // plain_morton: keys interleave x, y, z bit by bit; otherwise the bits are ordered by the size of the cell they halve and
 // bits finer than the typical record on their axis come last (see plan_bits in nori_lbvh.hip).
+// want8: also convert the tree into quantised eight-box nodes (Result::nodes8).
 // Returns 0 or a negative NORI_HIP_E* code with `err` set.
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
-          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, Result &res, std::string &err);
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, bool want8, Result &res, std::string &err);
 
 // radix sort of n (key, value) pairs of 32 bits each on key bits [0, end_bit); `temp` of sort_pairs_temp_bytes(n) bytes
 size_t sort_pairs_temp_bytes(uint32_t n);

@@ -216,14 +216,14 @@ __global__ void k_mark_last(NoriHipPrim *pout, uint32_t pos) { pout[pos].shape_f
 // binary nodes those are depends on the choices above them, so the tree is converted level by level: `queue` holds the binary
 // nodes of one level, a count pass and a scan number their inner children, an emit pass writes the level's nodes and the next
 // level's queue.  Node numbers: level after level, within a level in queue order (deterministic).
-struct Slots4 { float mn[4][3], mx[4][3]; uint32_t ref[4]; int n; };
+template <int N> struct Slots { float mn[N][3], mx[N][3]; uint32_t ref[N]; int n; };
 __device__ __forceinline__ float box_area(const float *mn, const float *mx) {
     const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
     return dx * dy + dy * dz + dz * dx;
 }
-__device__ __forceinline__ void open_greedy(const NoriHipNode *nodes, uint32_t b, Slots4 &s) {
+template <int N> __device__ __forceinline__ void open_greedy(const NoriHipNode *nodes, uint32_t b, Slots<N> &s) {
     const float inf = __builtin_huge_valf();
-    for (int k = 0; k < 4; ++k) { s.ref[k] = NORI_HIP_NO_CHILD; for (int a = 0; a < 3; ++a) { s.mn[k][a] = inf; s.mx[k][a] = -inf; } }
+    for (int k = 0; k < N; ++k) { s.ref[k] = NORI_HIP_NO_CHILD; for (int a = 0; a < 3; ++a) { s.mn[k][a] = inf; s.mx[k][a] = -inf; } }
     s.n = 0;
     const NoriHipNode w = nodes[b];
     for (int side = 0; side < 2; ++side) {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void open_greedy(const NoriHipNode *nodes, uint32_t b
         for (int a = 0; a < 3; ++a) { s.mn[s.n][a] = side ? w.rmin[a] : w.lmin[a]; s.mx[s.n][a] = side ? w.rmax[a] : w.lmax[a]; }
         s.ref[s.n++] = r;
     }
-    while (s.n < 4) {
+    while (s.n < N) {
         int best = -1; float best_area = -1.f;
         for (int k = 0; k < s.n; ++k) if (!(s.ref[k] & LB_LEAF)) { const float ar = box_area(s.mn[k], s.mx[k]); if (ar > best_area) { best_area = ar; best = k; } }
         if (best < 0) break;
@@ -246,10 +246,10 @@ __device__ __forceinline__ void open_greedy(const NoriHipNode *nodes, uint32_t b
         s.ref[best] = c.left; s.ref[best + 1] = c.right; s.n++;
     }
 }
-__global__ __launch_bounds__(256) void k_wide_count(uint32_t n_level, const uint32_t *queue, const NoriHipNode *nodes, uint32_t *count) {
+template <int N> __global__ __launch_bounds__(256) void k_wide_count(uint32_t n_level, const uint32_t *queue, const NoriHipNode *nodes, uint32_t *count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_level) return;
-    Slots4 s; open_greedy(nodes, queue[i], s);
+    Slots<N> s; open_greedy<N>(nodes, queue[i], s);
     uint32_t c = 0; for (int k = 0; k < s.n; ++k) if (!(s.ref[k] & LB_LEAF)) ++c;
     count[i] = c;
 }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_wide_emit(uint32_t n_level, const uint3
                                                    uint32_t *next_queue, float4 *out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_level) return;
-    Slots4 s; open_greedy(nodes, queue[i], s);
+    Slots<4> s; open_greedy<4>(nodes, queue[i], s);
     uint32_t o = offset[i];
     for (int k = 0; k < s.n; ++k) if (!(s.ref[k] & LB_LEAF)) { next_queue[o] = s.ref[k]; s.ref[k] = next_base + o; ++o; }
     float4 *q = out + 8 * (size_t) (level_base + i);
@@ -265,6 +265,58 @@ __global__ __launch_bounds__(256) void k_wide_emit(uint32_t n_level, const uint3
     q[3] = make_float4(s.mx[0][0], s.mx[1][0], s.mx[2][0], s.mx[3][0]); q[4] = make_float4(s.mx[0][1], s.mx[1][1], s.mx[2][1], s.mx[3][1]); q[5] = make_float4(s.mx[0][2], s.mx[1][2], s.mx[2][2], s.mx[3][2]);
     q[6] = make_float4(__uint_as_float(s.ref[0]), __uint_as_float(s.ref[1]), __uint_as_float(s.ref[2]), __uint_as_float(s.ref[3]));
     q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- eight-box nodes with quantised boxes (Trav::box_step8 in nori_device.h), for trees that do not fit the caches: the same
+// greedy opening up to eight slots, and the children's boxes stored as 8-bit offsets from the node's own box corner `p` in units of a
+// power of two per axis (after Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs through compressed wide
+// BVHs"): a 128-byte line decides eight descents instead of four.  Layout, 32 words:
+//   0-2  p (float3)        3  exponent bytes ex | ey << 8 | ez << 16 (biased: the unit on axis a is the float with exponent field e_a),
+//                             children in use << 24
+//   4-5  low x of children 0..7, a byte each | 6-7 low y | 8-9 low z | 10-11 high x | 12-13 high y | 14-15 high z
+//   16-23 child references   24-31 unused
+// Quantisation only enlarges: low corners round down, high corners up, each checked against the value p + q * unit as a float
+// evaluates it.  An unused slot has low = 255, high = 0 and reference NORI_HIP_NO_CHILD.
+// `need` carries, per queued node, the stack entries a traversal may hold when it arrives there (a visit of a node with c children
+// leaves at most c - 1 behind); the largest need + c - 1 over all nodes is what the traversal stack must hold.
+__global__ __launch_bounds__(256) void k_wide_emit8(uint32_t n_level, const uint32_t *queue, const uint32_t *need, const NoriHipNode *nodes, const uint32_t *offset, uint32_t level_base,
+                                                    uint32_t next_base, uint32_t *next_queue, uint32_t *next_need, uint4 *out, uint32_t *stack_max) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_level) return;
+    Slots<8> s; open_greedy<8>(nodes, queue[i], s);
+    const uint32_t held = need[i] + (uint32_t) (s.n > 0 ? s.n - 1 : 0);
+    atomicMax(stack_max, held);
+    uint32_t o = offset[i];
+    for (int k = 0; k < s.n; ++k) if (!(s.ref[k] & LB_LEAF)) { next_queue[o] = s.ref[k]; next_need[o] = held; s.ref[k] = next_base + o; ++o; }
+    float p[3], unit[3]; uint32_t eb[3];
+    uint32_t qlo[3][8], qhi[3][8];
+    for (int a = 0; a < 3; ++a) {
+        float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+        for (int k = 0; k < s.n; ++k) { lo = fminf(lo, s.mn[k][a]); hi = fmaxf(hi, s.mx[k][a]); }
+        p[a] = lo;
+        // the smallest power of two u with 254 u >= extent (254, not 255: room for the upward correction of a high corner)
+        const float ext = hi - lo;
+        int e = 0; (void) frexpf(ext > 0.f ? ext / 254.0f : 0.f, &e);                 // ext / 254 = m 2^e, m in [0.5, 1)  =>  2^e >= ext / 254
+        int be = e + 127; be = be < 1 ? 1 : (be > 254 ? 254 : be);
+        eb[a] = (uint32_t) be; unit[a] = __uint_as_float((uint32_t) be << 23);
+        for (int k = 0; k < 8; ++k) { qlo[a][k] = 255u; qhi[a][k] = 0u; }
+        for (int k = 0; k < s.n; ++k) {
+            float ql = floorf((s.mn[k][a] - lo) / unit[a]); ql = fminf(fmaxf(ql, 0.f), 255.f);
+            while (ql > 0.f && lo + ql * unit[a] > s.mn[k][a]) ql -= 1.f;
+            float qh = ceilf((s.mx[k][a] - lo) / unit[a]); qh = fminf(fmaxf(qh, 0.f), 255.f);
+            while (qh < 255.f && lo + qh * unit[a] < s.mx[k][a]) qh += 1.f;
+            qlo[a][k] = (uint32_t) ql; qhi[a][k] = (uint32_t) qh;
+        }
+    }
+    auto pack = [](const uint32_t *q) { return q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24); };
+    uint4 *q = out + 8 * (size_t) (level_base + i);
+    q[0] = make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16) | ((uint32_t) s.n << 24));
+    q[1] = make_uint4(pack(qlo[0]), pack(qlo[0] + 4), pack(qlo[1]), pack(qlo[1] + 4));
+    q[2] = make_uint4(pack(qlo[2]), pack(qlo[2] + 4), pack(qhi[0]), pack(qhi[0] + 4));
+    q[3] = make_uint4(pack(qhi[1]), pack(qhi[1] + 4), pack(qhi[2]), pack(qhi[2] + 4));
+    q[4] = make_uint4(s.ref[0], s.ref[1], s.ref[2], s.ref[3]);
+    q[5] = make_uint4(s.ref[4], s.ref[5], s.ref[6], s.ref[7]);
+    q[6] = make_uint4(0u, 0u, 0u, 0u); q[7] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 } // namespace
@@ -294,7 +346,7 @@ static BitPlan plan_bits(const float lo[3], const float hi[3], const long long l
 }
 
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
-          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, Result &res, std::string &err) {
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, bool want8, Result &res, std::string &err) {
     std::vector<void *> owned; hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() { for (void *p : owned) (void) hipFree(p); owned.clear(); if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); e0 = e1 = nullptr; };
 #define LCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); cleanup(); return NORI_HIP_EDEVICE; } } while (0)
@@ -400,7 +452,7 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
         uint32_t n_level = 1, base = 0, levels = 0;
         while (n_level > 0) {
             const unsigned lb = (n_level + 255u) / 256u;
-            hipLaunchKernelGGL(k_wide_count, dim3(lb), dim3(256), 0, stream, n_level, (const uint32_t *) qa, (const NoriHipNode *) nodes_tmp, cnt);
+            hipLaunchKernelGGL(k_wide_count<4>, dim3(lb), dim3(256), 0, stream, n_level, (const uint32_t *) qa, (const NoriHipNode *) nodes_tmp, cnt);
             LCHK(hipGetLastError());
             LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt, off, (int) n_level, stream));
             hipLaunchKernelGGL(k_wide_emit, dim3(lb), dim3(256), 0, stream, n_level, (const uint32_t *) qa, (const NoriHipNode *) nodes_tmp, (const uint32_t *) off, base, base + n_level, qb, wide_tmp);
@@ -418,6 +470,35 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
         LCHK(hipMalloc(&n4, (size_t) std::max<uint32_t>(res.n_nodes4, 1u) * 128));       // owned by the caller from here on
         res.nodes4 = n4;
         LCHK(hipMemcpyAsync(n4, wide_tmp, (size_t) res.n_nodes4 * 128, hipMemcpyDeviceToDevice, stream));
+        if (want8) {
+            // ... and as quantised eight-box nodes, the same way (the level queues, the scan's scratch and wide_tmp are reused)
+            uint32_t *na, *nb, *smax;
+            LCHK(alloc((void **) &na, ni * 4)); LCHK(alloc((void **) &nb, ni * 4)); LCHK(alloc((void **) &smax, 4));
+            LCHK(hipMemsetAsync(qa, 0, 4, stream)); LCHK(hipMemsetAsync(na, 0, 4, stream)); LCHK(hipMemsetAsync(smax, 0, 4, stream));
+            n_level = 1; base = 0; levels = 0;
+            while (n_level > 0) {
+                const unsigned lb = (n_level + 255u) / 256u;
+                hipLaunchKernelGGL(k_wide_count<8>, dim3(lb), dim3(256), 0, stream, n_level, (const uint32_t *) qa, (const NoriHipNode *) nodes_tmp, cnt);
+                LCHK(hipGetLastError());
+                LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt, off, (int) n_level, stream));
+                hipLaunchKernelGGL(k_wide_emit8, dim3(lb), dim3(256), 0, stream, n_level, (const uint32_t *) qa, (const uint32_t *) na, (const NoriHipNode *) nodes_tmp, (const uint32_t *) off, base,
+                                   base + n_level, qb, nb, reinterpret_cast<uint4 *>(wide_tmp), smax);
+                LCHK(hipGetLastError());
+                uint32_t h2[2];
+                LCHK(hipMemcpyAsync(&h2[0], cnt + (n_level - 1), 4, hipMemcpyDeviceToHost, stream));
+                LCHK(hipMemcpyAsync(&h2[1], off + (n_level - 1), 4, hipMemcpyDeviceToHost, stream));
+                LCHK(hipStreamSynchronize(stream));
+                base += n_level; n_level = h2[0] + h2[1]; ++levels;
+                std::swap(qa, qb); std::swap(na, nb);
+                if (base + (size_t) n_level > ni) { err = "lbvh: eight-box conversion overran its node bound"; cleanup(); return NORI_HIP_EDEVICE; }
+            }
+            res.n_nodes8 = base; res.depth8 = levels;
+            LCHK(hipMemcpyAsync(&res.stack8, smax, 4, hipMemcpyDeviceToHost, stream));
+            void *n8 = nullptr;
+            LCHK(hipMalloc(&n8, (size_t) std::max<uint32_t>(res.n_nodes8, 1u) * 128));   // owned by the caller from here on
+            res.nodes8 = n8;
+            LCHK(hipMemcpyAsync(n8, wide_tmp, (size_t) res.n_nodes8 * 128, hipMemcpyDeviceToDevice, stream));
+        }
     }
     uint32_t h_last[2];
     LCHK(hipMemcpyAsync(&h_last[0], used + (ni - 1), 4, hipMemcpyDeviceToHost, stream));

@@ -37,7 +37,7 @@ class Stats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("invalid_samples", C.c_uint64),
                 ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint64), ("render_ms", C.c_double),
                 ("extend_ms", C.c_double), ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("extend_boxes", C.c_uint64),
-                ("extend_prims", C.c_uint64)]
+                ("extend_prims", C.c_uint64), ("extend_visits", C.c_uint64), ("extend_width", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("lmin", "<f4", 3), ("lmax", "<f4", 3), ("rmin", "<f4", 3), ("rmax", "<f4", 3), ("left", "<u4"), ("right", "<u4"),
@@ -270,7 +270,8 @@ class Context:
         """the kernel bench.py's roofline is quoted on (the trace stage of the wavefront pipeline)"""
         if os.environ.get("NORI_HIP_MERGE", "1") == "0":
             return "k_trace_pool<TK_EXTEND>"
-        return "k_trace_pool4" if os.environ.get("NORI_HIP_WIDE", "1") != "0" else "k_trace_pool<TK_BOTH>"
+        width = self.stats()["extend_width"]
+        return {8: "k_trace_pool8", 4: "k_trace_pool4"}.get(width, "k_trace_pool<TK_BOTH>")
 
     def clear_film(self):
         _hchk(self.L.nori_hip_clear_film(self.h))

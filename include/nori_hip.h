@@ -181,6 +181,8 @@ typedef struct NoriHipStats {
     double   extend_ms;            /* device time of the extend-stage launches (k_trace_pool<closest>) since the last reset_stats, HIP events */
     uint64_t extend_launches;      /* how many launches extend_ms covers (0: the single-kernel pipeline ran) */
     uint64_t extend_rays, extend_boxes, extend_prims;   /* work of those launches */
+    uint64_t extend_visits;        /* node fetches of those launches (four- and eight-box trace stages; 0 for the two-box walk, which fetches extend_boxes / 2) */
+    uint64_t extend_width;         /* boxes per node the trace stage of the last render walked: 2, 4, or 8 (quantised boxes) */
 } NoriHipStats;
 
 typedef struct NoriHipContext NoriHipContext;

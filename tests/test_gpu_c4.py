@@ -75,16 +75,20 @@ def test_c4_reduced_hits_and_li_against_oracle_with_the_reference_order_tree(c4_
     hs.close()
 
 
-def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small):
+@pytest.mark.parametrize("width", ["4", "8"])
+def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small, width):
+    """width 8: the device-built tree as quantised eight-box nodes (NORI_HIP_WIDE=8; boxes only ever enlarged)"""
     W = H = 96
     hs = NH.HostScene(c4_small, W, H, 4)
     ctx = hs.preprocess()
-    os.environ["NORI_HIP_BVH"] = "device"
+    env = {"NORI_HIP_BVH": "device", "NORI_HIP_WIDE": width, "NORI_HIP_SORT": "1"}      # (rays ordered and dealt by XCD, as at full size)
+    os.environ.update(env)
     try:
         hd = NH.HostScene(c4_small, W, H, 4)
         cd = hd.preprocess()
     finally:
-        del os.environ["NORI_HIP_BVH"]
+        for k in env:
+            del os.environ[k]
     bi = cd.build_info()
     assert bi["n_used"] > 0 and 0 < bi["depth"] <= 62
     rays, bounce = camera_and_bounce_rays(ctx, W, H, 20000, 4)
@@ -100,6 +104,7 @@ def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small):
     # the two trees render the same image up to the ties
     ctx.clear_film(); ctx.render(0, 4); cd.clear_film(); cd.render(0, 4)
     fa, fb = ctx.read_film(), cd.read_film()
+    assert cd.stats()["extend_width"] == int(width)
     assert np.array_equal(fa[:, :, 3], fb[:, :, 3])
     assert abs(fa[:, :, :3].sum() - fb[:, :, :3].sum()) < 2e-3 * fa[:, :, :3].sum()
     hs.close(); hd.close()

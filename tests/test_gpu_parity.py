@@ -228,6 +228,9 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_DYN="50", NORI_HIP_DYN_TRIES="8", NORI_HIP_POOL="1000")]    # a grid of fewer than 8 workgroups
     configs += [dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1"),                                 # rays ordered by the cell of their path vertex
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_POOL="1000", NORI_HIP_FINISH="1"),
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="0"),               # ... dealt round-robin instead of by XCD
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="3", NORI_HIP_POOL="4096"),     # 24 chunks of 2-3 batches, positions past the end
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="255", NORI_HIP_DYN="50", NORI_HIP_DYN_TRIES="8", NORI_HIP_POOL="9000"),   # more chunks than batches; half from the queues
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0"),                                 # trace stage over the 64-byte two-box nodes
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0", NORI_HIP_SPEC="0", NORI_HIP_POOL="4096")]
     # Any-hit rays normally enter the nearer child first (the answer does not depend on the order, the number of records tested
@@ -526,20 +529,24 @@ def test_baseline_config0_image_against_oracle_and_the_reference_binary(loaded):
     assert abs(st["closest_rays"] - ost["closest"]) < 2e-3 * ost["closest"] and abs(st["shadow_rays"] - ost["shadow"]) < 2e-3 * ost["shadow"]
 
 
-@pytest.mark.parametrize("name", ["cbox", "table", "dragon", "cbox_subsurface", "texture_bump"])
+@pytest.mark.parametrize("name", ["cbox", "table", "dragon", "cbox_subsurface", "texture_bump", "cbox/8", "table/8", "dragon/8"])
 def test_device_built_bvh_gives_the_reference_hits(name):
     """nori_hip_upload_scene_build: a linear BVH built on the GPU from the records in scene order.  Not the
     reference's tree, so the bar is on results: the closest primitive is tree-independent except where two primitives tie
     in t (shared edges), any-hit answers are tree-independent."""
+    # ".../8": the tree walked through quantised eight-box nodes (NORI_HIP_WIDE=8) by nori_hip_trace and by the render's kernels
+    name, _, width = name.partition("/")
     xml = os.path.join(SCENES, {**SCENE_XML, **IMAGE_XML}[name])
     W, H = 64, 48
-    os.environ["NORI_HIP_BVH"] = "device"
+    env = {"NORI_HIP_BVH": "device", **({"NORI_HIP_WIDE": width} if width else {})}
+    os.environ.update(env)
     try:
         hd = NH.HostScene(xml, W, H, 1)
         assert hd.info()["nodes"] == 0                                          # no host build happened
         cd = hd.preprocess()
     finally:
-        del os.environ["NORI_HIP_BVH"]
+        for k in env:
+            del os.environ[k]
     bi = cd.build_info()
     n = hd.info()["prims"]
     assert 0 < bi["n_nodes"] <= max(n - 1, 0) and bi["n_used"] == bi["n_nodes"] and 0 < bi["depth"] <= 62, bi
@@ -568,6 +575,7 @@ def test_device_built_bvh_gives_the_reference_hits(name):
     cs = hs.preprocess()
     cs.clear_film(); cs.render(0, spp)
     cd.clear_film(); cd.render(0, spp)
+    assert cd.stats()["extend_width"] == (int(width) if width else 0 if name == "texture_bump" else 4)      # (0: the single-kernel pipeline ran)
     a, b = cs.read_film(), cd.read_film()
     assert np.array_equal(a[:, :, 3], b[:, :, 3])
     close = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(2)
