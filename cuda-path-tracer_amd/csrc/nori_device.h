@@ -289,10 +289,10 @@ template <bool ANY> struct Trav {
 #define ND_CE4(A, B) { const bool sw_ = key[B] < key[A]; const float tk_ = sw_ ? key[B] : key[A]; key[B] = sw_ ? key[A] : key[B]; key[A] = tk_; \
                        const float tn_ = sw_ ? nr[B] : nr[A]; nr[B] = sw_ ? nr[A] : nr[B]; nr[A] = tn_; \
                        const uint32_t tr_ = sw_ ? ref[B] : ref[A]; ref[B] = sw_ ? ref[A] : ref[B]; ref[A] = tr_; }
-    template <typename StackT> __device__ __forceinline__ void box4_finish(float nr[4], const bool hit[4], uint32_t ref[4], StackT &stk, const bool ordered) {
+    template <typename StackT> __device__ __forceinline__ void box4_finish(float nr[4], const bool hit[4], uint32_t ref[4], StackT &stk, const bool ordered, const bool far = false) {
         float key[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) key[k] = hit[k] ? (ordered ? nr[k] : (float) k) : ND_INF;
+        for (int k = 0; k < 4; ++k) key[k] = hit[k] ? (ordered ? (far ? -nr[k] : nr[k]) : (float) k) : ND_INF;
         ND_CE4(0, 1) ND_CE4(2, 3) ND_CE4(0, 2) ND_CE4(1, 3) ND_CE4(1, 2)
         const int n = (int) hit[0] + (int) hit[1] + (int) hit[2] + (int) hit[3];
         if (n > 3) stk.push(sp++, make_uint2(ref[3], __float_as_uint(nr[3])));
@@ -312,7 +312,7 @@ template <bool ANY> struct Trav {
     // direction components all normal numbers: min/max form, as box_compute_fast
     // (both forms return the number of boxes the node holds, for the statistics)
     // `sort` (wave-uniform): false when no lane of the wave is `ordered`
-    template <typename StackT> __device__ __forceinline__ uint32_t box_step4_fast(const float4 *nodes4, StackT &stk, const bool ordered, const bool sort = true) {
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step4_fast(const float4 *nodes4, StackT &stk, const bool ordered, const bool sort = true, const bool far = false) {
         const float4 *q = nodes4 + 8 * (size_t) cur;
         const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5]; const float4 cr = q[6];
         const float lx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ly[4] = {mny.x, mny.y, mny.z, mny.w}, lz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
@@ -329,11 +329,11 @@ template <bool ANY> struct Trav {
             nr[k] = nn; hit[k] = (nn <= ff) & (mint <= ff) & (nn <= maxt) & (ref[k] != NORI_HIP_NO_CHILD);
         }
         const uint32_t n_valid = (uint32_t) (ref[0] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[1] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[2] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[3] != NORI_HIP_NO_CHILD);
-        if (sort) box4_finish(nr, hit, ref, stk, ordered); else box4_finish_inorder(nr, hit, ref, stk);
+        if (sort) box4_finish(nr, hit, ref, stk, ordered, far); else box4_finish_inorder(nr, hit, ref, stk);
         return n_valid;
     }
     // any ray: the reference's test as written (zero, denormal or NaN direction components)
-    template <typename StackT> __device__ __forceinline__ uint32_t box_step4(const float4 *nodes4, StackT &stk, const bool ordered) {
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step4(const float4 *nodes4, StackT &stk, const bool ordered, const bool far = false) {
         const float4 *q = nodes4 + 8 * (size_t) cur;
         const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5]; const float4 cr = q[6];
         const float lx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ly[4] = {mny.x, mny.y, mny.z, mny.w}, lz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
@@ -347,7 +347,7 @@ template <bool ANY> struct Trav {
             nr[k] = nn; hit[k] = h & (ref[k] != NORI_HIP_NO_CHILD);
         }
         const uint32_t n_valid = (uint32_t) (ref[0] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[1] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[2] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[3] != NORI_HIP_NO_CHILD);
-        box4_finish(nr, hit, ref, stk, ordered);
+        box4_finish(nr, hit, ref, stk, ordered, far);
         return n_valid;
     }
     // ---- eight-box nodes with quantised boxes (device-built trees that do not fit the caches; layout: lbvh::k_wide_emit8) -----------
@@ -534,12 +534,13 @@ template <bool ANY, typename StackT>
 __device__ __forceinline__ bool trace4(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
     Trav<ANY> tv;
     const bool ordered = (ANY && (sc.ordered & 2)) || (sc.ordered & 1);
+    const bool far = ANY && (sc.ordered & 4);
     if (tv.begin(sc, ray_in, n_nodes)) tv.cur = sc.root4;
     for (;;) {
         const unsigned long long m_in = __ballot(tv.at_inner());
         if (m_in) {
-            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step4_fast(sc.nodes4, stk, ordered); }
-            else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step4(sc.nodes4, stk, ordered); else n_nodes += tv.box_step4_fast(sc.nodes4, stk, ordered); }
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step4_fast(sc.nodes4, stk, ordered, true, far); }
+            else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step4(sc.nodes4, stk, ordered, far); else n_nodes += tv.box_step4_fast(sc.nodes4, stk, ordered, true, far); }
         }
         const unsigned long long m_lf = __ballot(tv.at_leaf());
         if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) { if (tv.at_leaf()) tv.prim_step(sc, n_prims); }

@@ -809,8 +809,9 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
             } else if (WIDE) {
                 n_visits += (unsigned int) __popcll(m_in);
                 const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
-                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort); }
-                else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
+                const bool far = ((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 4);
+                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort, far); }
+                else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord, far);
             } else {
                 n_boxes += 2u * (unsigned int) __popcll(m_in);
                 if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
@@ -847,8 +848,9 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
                 } else if (WIDE) {
                     n_visits += (unsigned int) __popcll(m_in2);
                     const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
-                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort); }
-                    else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord);
+                    const bool far = ((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 4);
+                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort, far); }
+                    else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord, far);
                 } else {
                     n_boxes += 2u * (unsigned int) __popcll(m_in2);
                     if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) tv.box_step_fast(nodes, stk, dummy, ord); }
@@ -1214,6 +1216,12 @@ struct NoriHipContext {
     int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
+    int align_leaves = -1;            // NORI_HIP_LBVH_ALIGN: 1 / 0 = device-built trees with leaves of at most two records place them so that no leaf straddles a
+                                      // 128-byte line (two of every eight record positions stay empty) or in plain sorted order; -1 = from a million records on
+    int any_far = -1;                 // NORI_HIP_ANYORDER=far / near: any-hit rays enter first the child whose box they reach last / first (four-box nodes; the answer
+                                      // is the same for every order).  A shadow ray runs from the light to the shaded point (src/arealight.cpp:77-82), and on a scene
+                                      // whose occluders crowd around the shaded points the far end finds one sooner: 10 M-triangle workload 395.7 -> 383.9 ms, cbox
+                                      // 26.7 -> 28.1, table / dragon / subsurface within 1 %.  -1: far when the tree does not fit the caches, near otherwise
     bool any_near = true;             // NORI_HIP_ANYORDER=reference: any-hit rays walk the tree in the reference's order too (then every schedule and
                                       // node width tests the same records; by default they enter the nearer child first, which finds occluders sooner)
     bool ordered = false;             // NORI_HIP_ORDER=near: nearer child first in traversal (see DevScene::ordered)
@@ -1302,6 +1310,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_WIDE")) { const int v = atoi(e); c->wide = v != 0; c->wide8 = v == 8 ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
+    if (const char *e = getenv("NORI_HIP_LBVH_ALIGN")) c->align_leaves = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("NORI_HIP_XCD")) { int v = atoi(e); if (v >= 0 && v <= 255) c->xcd_chunks = v; }
     if (const char *e = getenv("NORI_HIP_DYN")) { int v = atoi(e); if (v >= 0 && v <= 90) c->dyn_pct = v; }
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
@@ -1312,7 +1321,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
     if (const char *e = getenv("NORI_HIP_ORDER")) c->ordered = std::string(e) == "near";
-    if (const char *e = getenv("NORI_HIP_ANYORDER")) c->any_near = std::string(e) != "reference";
+    if (const char *e = getenv("NORI_HIP_ANYORDER")) { c->any_near = std::string(e) != "reference"; c->any_far = std::string(e) == "far" ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_PRIM_LANES")) { int v = atoi(e); if (v >= 1 && v <= 64) c->prim_lanes = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 768 || v == 1024) c->trace_threads = v; }
     if (const char *e = getenv("NORI_HIP_MERGE")) c->merge_trace = atoi(e) != 0;
@@ -1488,7 +1497,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     // Renumber the inner nodes so that the top of the tree comes first, in breadth-first order: kernels keep a prefix
     // of the node array in LDS and test `index < cached`.  Only the numbering changes; boxes, child order and the
     // leaf records are the caller's.
-    uint32_t root = d->root, n_top = 0;
+    uint32_t root = d->root, n_top = 0, n_records = d->n_prims;
     float root_min[3] = {d->root_min[0], d->root_min[1], d->root_min[2]}, root_max[3] = {d->root_max[0], d->root_max[1], d->root_max[2]};
     ctx->lbvh = lbvh::Result();
     if (device_build) {
@@ -1501,10 +1510,18 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         hipError_t e3_ = hipMalloc((void **) &ctx->d_nodes, (size_t) std::max<uint32_t>(d->n_prims - 1, 1u) * sizeof(NoriHipNode));
         std::string lerr;
         rc = (e1_ != hipSuccess || e2_ != hipSuccess || e3_ != hipSuccess) ? NORI_HIP_EDEVICE
-             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf ? ctx->lbvh_leaf : (d->n_prims >= 1000000u ? 2u : 3u), ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->wide && ctx->wide8 == 1 && !ext, ctx->lbvh, lerr);
+             : lbvh::build(ctx->stream, d->n_prims, tmp_prims, tmp_shade, ctx->d_prims, ctx->d_shade, ctx->d_nodes, ctx->lbvh_leaf ? ctx->lbvh_leaf : (d->n_prims >= 1000000u ? 2u : 3u), ctx->lbvh_big, ND_STACK - 2, ctx->lbvh_plain, ctx->wide && ctx->wide8 == 1 && !ext,
+                           ctx->align_leaves >= 0 ? ctx->align_leaves != 0 : d->n_prims >= 1000000u, ctx->lbvh, lerr);
         hipFree(tmp_prims); hipFree(tmp_shade);
-        if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; hipFree(ctx->lbvh.nodes8); ctx->lbvh.nodes8 = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
+        if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; hipFree(ctx->lbvh.nodes8); ctx->lbvh.nodes8 = nullptr; hipFree(ctx->lbvh.prims_al); hipFree(ctx->lbvh.shade_al); ctx->lbvh.prims_al = ctx->lbvh.shade_al = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
         ctx->d_nodes4 = (float4 *) ctx->lbvh.nodes4; ctx->n_nodes4 = ctx->lbvh.n_nodes4; ctx->lbvh.nodes4 = nullptr;
+        n_records = d->n_prims;
+        if (ctx->lbvh.prims_al) {
+            // the records placed leaf by leaf (no leaf straddles a line): they replace the arrays in sorted order
+            hipFree(ctx->d_prims); hipFree(ctx->d_shade);
+            ctx->d_prims = (NoriHipPrim *) ctx->lbvh.prims_al; ctx->d_shade = (NoriHipShadePrim *) ctx->lbvh.shade_al; ctx->lbvh.prims_al = ctx->lbvh.shade_al = nullptr;
+            n_records = ctx->lbvh.n_positions;
+        }
         // up to three stack entries per four-box level: deeper trees are walked through their two-box nodes
         if (3u * ctx->lbvh.depth4 > (uint32_t) (ND_STACK - 2)) { hipFree(ctx->d_nodes4); ctx->d_nodes4 = nullptr; ctx->n_nodes4 = 0; }
         // quantised eight-box nodes (NORI_HIP_WIDE=8), if their traversal fits the stack; scenes with images or subsurface shapes
@@ -1557,14 +1574,18 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     if ((rc = upload(ctx->d_tex_data, d->tex_data, d->n_textures ? (size_t) d->n_tex_bytes : 0))) return rc;
     ctx->ext = ext; ctx->has_ss = false;
     for (uint32_t i = 0; i < d->n_shapes; ++i) if (d->shapes[i].bsdf == NORI_HIP_BSDF_SUBSURFACE) ctx->has_ss = true;
-    ctx->n_prims = d->n_prims; ctx->n_nodes = device_build ? ctx->lbvh.n_nodes : d->n_nodes;
+    ctx->n_prims = n_records; ctx->n_nodes = device_build ? ctx->lbvh.n_nodes : d->n_nodes;
     DevScene &sc = ctx->sc;
     sc.nodes = ctx->d_nodes; sc.prims = reinterpret_cast<const float4 *>(ctx->d_prims); sc.shade = ctx->d_shade;
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
     sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
     // a device-built tree has no reference child order to keep: the nearer child is entered first
     sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u; sc.nodes8 = ctx->d_nodes8;
-    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.ordered = ((ctx->ordered || device_build) ? 1 : 0) | (ctx->any_near ? 2 : 0);
+    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; {
+        const size_t tree_b = (size_t) (ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
+        const bool far = ctx->any_far >= 0 ? ctx->any_far != 0 : tree_b > ((size_t) 192 << 20);
+        sc.ordered = ((ctx->ordered || device_build) ? 1 : 0) | (ctx->any_near ? 2 : 0) | (far ? 4 : 0);
+    }
     for (int i = 0; i < 3; ++i) { sc.root_min[i] = root_min[i]; sc.root_max[i] = root_max[i]; }
     sc.cam = d->camera;
     sc.inv_w = 1.0f / (float) d->camera.width; sc.inv_h = 1.0f / (float) d->camera.height;

@@ -23,6 +23,8 @@ struct Result {
     uint32_t n_nodes8 = 0;         // owned by the caller; root = node 0
     uint32_t depth8 = 0;           // levels of eight-box nodes
     uint32_t stack8 = 0;           // most stack entries a traversal of the eight-box nodes can hold at once
+    void *prims_al = nullptr, *shade_al = nullptr;   // (align_leaves) the records placed so that no leaf straddles a 128-byte line, hipMalloc'ed here, owned by the
+    uint32_t n_positions = 0;      // caller, n_positions records each (unused positions are zero records that no leaf names); prims_out / shade_out are then unused
 };
 
 // prims_in / shade_in: n records in any order (bit 31 of shape_flags ignored).  prims_out / shade_out: n records in
@@ -30,10 +32,11 @@ struct Result {
 // longer than `big` times the scene on some axis go into a subtree of their own under the root (0: off).
 // plain_morton: keys interleave x, y, z bit by bit; otherwise the bits are ordered by the size of the cell they halve and
 // bits finer than the typical record on their axis come last (see plan_bits in nori_lbvh.hip).
+// align_leaves (leaf_max <= 2 only): see Result::prims_al.
 // want8: also convert the tree into quantised eight-box nodes (Result::nodes8).
 // Returns 0 or a negative NORI_HIP_E* code with `err` set.
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
-          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, bool want8, Result &res, std::string &err);
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, bool want8, bool align_leaves, Result &res, std::string &err);
 
 // radix sort of n (key, value) pairs of 32 bits each on key bits [0, end_bit); `temp` of sort_pairs_temp_bytes(n) bytes
 size_t sort_pairs_temp_bytes(uint32_t n);

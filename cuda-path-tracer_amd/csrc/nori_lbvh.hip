@@ -160,17 +160,38 @@ __global__ __launch_bounds__(256) void k_depth(uint32_t n, const uint32_t *paren
     if ((threadIdx.x & 63u) == 0u) atomicMax(max_depth, d);
 }
 
-__global__ __launch_bounds__(256) void k_reorder(uint32_t n, const uint32_t *vals, const NoriHipPrim *pin, const NoriHipShadePrim *sin, NoriHipPrim *pout, NoriHipShadePrim *sout) {
+// Where sorted record i goes.  Plain: position i.  Aligned (leaves of one or two records): leaf number c takes the cell of two
+// positions 8 (c / 3) + 3 (c % 3) - positions 0-1, 3-4 and 6-7 of every run of eight 48-byte records, none of which crosses a
+// 128-byte line (positions 2 and 5 do, and stay empty): a leaf visit then costs one HBM line instead of 1.5 on average.
+// leaf_idx = exclusive prefix sum of leaf_start.
+__device__ __forceinline__ uint32_t place(uint32_t i, const uint32_t *leaf_start, const uint32_t *leaf_idx) {
+    if (!leaf_idx) return i;
+    const bool st = leaf_start[i] != 0u;
+    const uint32_t c = st ? leaf_idx[i] : leaf_idx[i] - 1u;
+    return 8u * (c / 3u) + 3u * (c % 3u) + (st ? 0u : 1u);
+}
+__global__ __launch_bounds__(256) void k_reorder(uint32_t n, const uint32_t *vals, const NoriHipPrim *pin, const NoriHipShadePrim *sin, NoriHipPrim *pout, NoriHipShadePrim *sout,
+                                                 const uint32_t *leaf_start, const uint32_t *leaf_idx, const uint32_t *leaf_end) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t src = vals[i];
     NoriHipPrim p = pin[src]; p.shape_flags &= 0x7fffffffu;
-    pout[i] = p; sout[i] = sin[src];
+    if (leaf_end && leaf_end[i]) p.shape_flags |= 0x80000000u;
+    const uint32_t dst = place(i, leaf_start, leaf_idx);
+    pout[dst] = p; sout[dst] = sin[src];
+}
+// leaf references of the emitted nodes from sorted positions to placed ones
+__global__ __launch_bounds__(256) void k_place_refs(uint32_t n_inner, const uint32_t *used, NoriHipNode *nodes, const uint32_t *leaf_start, const uint32_t *leaf_idx) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner || !used[i]) return;
+    NoriHipNode &w = nodes[i];
+    if (w.left != NORI_HIP_NO_CHILD && (w.left & LB_LEAF)) w.left = LB_LEAF | place(w.left & 0x7fffffffu, leaf_start, leaf_idx);
+    if (w.right != NORI_HIP_NO_CHILD && (w.right & LB_LEAF)) w.right = LB_LEAF | place(w.right & 0x7fffffffu, leaf_start, leaf_idx);
 }
 
 __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t leaf_max, const uint32_t *vals, const float4 *pmin, const float4 *pmax, const uint32_t *left,
                                               const uint32_t *right, const uint32_t *first, const uint32_t *last, const float *nbox, NoriHipNode *nodes,
-                                              NoriHipPrim *pout, uint32_t *used) {
+                                              uint32_t *leaf_start, uint32_t *leaf_end, uint32_t *used) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     NoriHipNode w;
@@ -184,12 +205,12 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t leaf_max, con
             const float4 a = pmin[vals[pos]], b = pmax[vals[pos]];
             mn[0] = a.x; mn[1] = a.y; mn[2] = a.z; mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
             ref = LB_LEAF | pos; count = 1;
-            atomicOr(&pout[pos].shape_flags, 0x80000000u);
+            leaf_start[pos] = 1u; leaf_end[pos] = 1u;
         } else {
             const float *q = nbox + 8 * (size_t) c;
             for (int a = 0; a < 3; ++a) { mn[a] = q[a]; mx[a] = q[4 + a]; }
             const uint32_t sz = last[c] - first[c] + 1u;
-            if (sz <= leaf_max) { ref = LB_LEAF | first[c]; count = sz; atomicOr(&pout[last[c]].shape_flags, 0x80000000u); }
+            if (sz <= leaf_max) { ref = LB_LEAF | first[c]; count = sz; leaf_start[first[c]] = 1u; leaf_end[last[c]] = 1u; }
             else { ref = c; count = 0; }
         }
         if (side) { w.right = ref; w.rcount = count; } else { w.left = ref; w.lcount = count; }
@@ -346,7 +367,7 @@ static BitPlan plan_bits(const float lo[3], const float hi[3], const long long l
 }
 
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
-          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, bool want8, Result &res, std::string &err) {
+          NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, bool want8, bool align_leaves, Result &res, std::string &err) {
     std::vector<void *> owned; hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() { for (void *p : owned) (void) hipFree(p); owned.clear(); if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); e0 = e1 = nullptr; };
 #define LCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); cleanup(); return NORI_HIP_EDEVICE; } } while (0)
@@ -369,7 +390,7 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
         std::vector<uint32_t> ident(n); for (uint32_t i = 0; i < n; ++i) ident[i] = i;
         uint32_t *vals; LCHK(alloc((void **) &vals, (size_t) n * 4));
         LCHK(hipMemcpyAsync(vals, ident.data(), (size_t) n * 4, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals, prims_in, shade_in, prims_out, shade_out);
+        hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals, prims_in, shade_in, prims_out, shade_out, (const uint32_t *) nullptr, (const uint32_t *) nullptr, (const uint32_t *) nullptr);
         hipLaunchKernelGGL(k_mark_last, dim3(1), dim3(1), 0, stream, prims_out, n - 1);
         LCHK(hipGetLastError());
         std::vector<float4> hmn(n), hmx(n);
@@ -429,16 +450,38 @@ int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const Nor
         hipLaunchKernelGGL(k_refit_pass, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, pass, (const uint32_t *) vals_s, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) left,
                            (const uint32_t *) right, nbox, arrived);
     LCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals_s, prims_in, shade_in, prims_out, shade_out);
-    LCHK(hipGetLastError());
-    NoriHipNode *nodes_tmp; uint32_t *used, *new_index;
+    NoriHipNode *nodes_tmp; uint32_t *used, *new_index, *leaf_start, *leaf_end, *leaf_idx = nullptr;
     LCHK(alloc((void **) &nodes_tmp, ni * sizeof(NoriHipNode))); LCHK(alloc((void **) &used, ni * 4)); LCHK(alloc((void **) &new_index, ni * 4));
+    LCHK(alloc((void **) &leaf_start, (size_t) n * 4)); LCHK(alloc((void **) &leaf_end, (size_t) n * 4));
+    LCHK(hipMemsetAsync(leaf_start, 0, (size_t) n * 4, stream)); LCHK(hipMemsetAsync(leaf_end, 0, (size_t) n * 4, stream));
     hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, n, leaf_max, (const uint32_t *) vals_s, (const float4 *) pmin, (const float4 *) pmax, (const uint32_t *) left,
-                       (const uint32_t *) right, (const uint32_t *) first, (const uint32_t *) last, (const float *) nbox, nodes_tmp, prims_out, used);
+                       (const uint32_t *) right, (const uint32_t *) first, (const uint32_t *) last, (const float *) nbox, nodes_tmp, leaf_start, leaf_end, used);
     LCHK(hipGetLastError());
     size_t scan_bytes = 0; void *scan_tmp = nullptr;
-    LCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, used, new_index, (int) ni, stream));
+    LCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, leaf_start, new_index, (int) n, stream));       // (the larger of the scans made with this scratch)
     LCHK(alloc(&scan_tmp, scan_bytes));
+    NoriHipPrim *p_dst = prims_out; NoriHipShadePrim *s_dst = shade_out;
+    if (align_leaves && leaf_max <= 2u) {
+        LCHK(alloc((void **) &leaf_idx, (size_t) n * 4));
+        LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, leaf_start, leaf_idx, (int) n, stream));
+        uint32_t h2[2];
+        LCHK(hipMemcpyAsync(&h2[0], leaf_start + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        LCHK(hipMemcpyAsync(&h2[1], leaf_idx + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        LCHK(hipStreamSynchronize(stream));
+        const uint64_t n_leaves = (uint64_t) h2[0] + h2[1], n_pos = ((n_leaves + 2u) / 3u) * 8u;
+        if (n_pos >= 0x7fffffffull) { err = "lbvh: too many records to place leaf by leaf"; cleanup(); return NORI_HIP_EINVAL; }
+        void *pa = nullptr, *sa = nullptr;
+        LCHK(hipMalloc(&pa, (size_t) n_pos * sizeof(NoriHipPrim))); res.prims_al = pa;                           // owned by the caller from here on
+        LCHK(hipMalloc(&sa, (size_t) n_pos * sizeof(NoriHipShadePrim))); res.shade_al = sa;
+        LCHK(hipMemsetAsync(pa, 0, (size_t) n_pos * sizeof(NoriHipPrim), stream)); LCHK(hipMemsetAsync(sa, 0, (size_t) n_pos * sizeof(NoriHipShadePrim), stream));
+        res.n_positions = (uint32_t) n_pos;
+        p_dst = (NoriHipPrim *) pa; s_dst = (NoriHipShadePrim *) sa;
+        hipLaunchKernelGGL(k_place_refs, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) used, nodes_tmp, (const uint32_t *) leaf_start, (const uint32_t *) leaf_idx);
+        LCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_reorder, dim3(blocks), dim3(256), 0, stream, n, (const uint32_t *) vals_s, prims_in, shade_in, p_dst, s_dst, (const uint32_t *) leaf_start, (const uint32_t *) leaf_idx,
+                       (const uint32_t *) leaf_end);
+    LCHK(hipGetLastError());
     LCHK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, used, new_index, (int) ni, stream));
     hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(256), 0, stream, (uint32_t) ni, (const uint32_t *) used, (const uint32_t *) new_index, (const NoriHipNode *) nodes_tmp, nodes_out);
     LCHK(hipGetLastError());

@@ -75,13 +75,17 @@ def test_c4_reduced_hits_and_li_against_oracle_with_the_reference_order_tree(c4_
     hs.close()
 
 
-@pytest.mark.parametrize("width", ["4", "8"])
-def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small, width):
-    """width 8: the device-built tree as quantised eight-box nodes (NORI_HIP_WIDE=8; boxes only ever enlarged)"""
+@pytest.mark.parametrize("width,extra", [("4", {}), ("8", {}),
+                                         ("4", {"NORI_HIP_LBVH_ALIGN": "1", "NORI_HIP_LBVH_LEAF": "2", "NORI_HIP_ANYORDER": "far"})],
+                         ids=["four-box", "eight-box", "full-size-defaults"])
+def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small, width, extra):
+    """width 8: the device-built tree as quantised eight-box nodes (NORI_HIP_WIDE=8; boxes only ever enlarged).
+    full-size-defaults: what a tree of a million records or more gets by itself - leaves of two records placed so that none
+    straddles a 128-byte line (two of eight record positions stay empty), any-hit rays entering the farthest child first."""
     W = H = 96
     hs = NH.HostScene(c4_small, W, H, 4)
     ctx = hs.preprocess()
-    env = {"NORI_HIP_BVH": "device", "NORI_HIP_WIDE": width, "NORI_HIP_SORT": "1"}      # (rays ordered and dealt by XCD, as at full size)
+    env = {"NORI_HIP_BVH": "device", "NORI_HIP_WIDE": width, "NORI_HIP_SORT": "1", **extra}      # (rays ordered and dealt by XCD, as at full size)
     os.environ.update(env)
     try:
         hd = NH.HostScene(c4_small, W, H, 4)
