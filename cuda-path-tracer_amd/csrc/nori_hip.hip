@@ -1234,7 +1234,7 @@ struct NoriHipContext {
     int xcd_chunks = -1;              // NORI_HIP_XCD: chunks of the sorted ray order per XCD in the trace stage's deal (0 = off, -1 = 64)
     int dyn_tries = 3;                // NORI_HIP_DYN_TRIES: queues a finishing wave tries (1..8)
     int dyn_pct = 15;                 // NORI_HIP_DYN: percent of the trace stage's rounds of batches that are handed out dynamically at the end
-    int box2 = -1;                    // (-1 = 36, or 0 when the tree does not fit the caches) NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
+    int box2 = -1;                    // (-1 = 36) NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 1, thr_prim = 1, thr_refill = 12;   // k_trace_pool step thresholds (lanes), NORI_HIP_THR
@@ -1882,7 +1882,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
     const unsigned int xcd_chunks = (unsigned int) (ctx->xcd_chunks >= 0 ? ctx->xcd_chunks : 64);             // sorted rays: chunks of the sorted order per XCD (0: plain round-robin deal)
-    const unsigned int trace_box2 = (unsigned int) (ctx->box2 >= 0 ? ctx->box2 : (big_tree ? 0 : 36)) | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16) | (xcd_chunks << 20);
+    const unsigned int trace_box2 = (unsigned int) (ctx->box2 >= 0 ? ctx->box2 : 36) | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16) | (xcd_chunks << 20);
     const bool spec = ctx->spec >= 0 ? ctx->spec != 0 : !big_tree;
     const size_t trace_lds = trace_fixed;
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
