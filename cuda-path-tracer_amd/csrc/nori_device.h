@@ -100,6 +100,7 @@ struct DevScene {
     int ordered;                       // bit 0 clear: the reference's child order (left first; decides ties, bit-exact hits).  set: nearer child first —
                                        // fewer box tests, same hit except where two primitives tie within rounding (NORI_HIP_ORDER=near)
                                        // bit 1 set (default): any-hit rays enter the nearer child first whatever bit 0 says (same answer for every order)
+    int cull_zero;                     // emitter samples whose term is exactly zero get no shadow ray (shade_finish)
     int prim_lanes;                    // run-to-completion traversal: lanes that must wait at a leaf before a record step is issued
     uint32_t n_top;                    // nodes [0, n_top) are the top of the tree in breadth-first order (LDS cache candidates)
     float root_min[3], root_max[3];
@@ -965,7 +966,7 @@ __device__ __forceinline__ F3 env_miss(const DevScene &sc, F3 dir, F3 t, float l
     return (wmat > 0.0f) ? (wmat * t) * flight : f3(0.f);
 }
 // What the shading of one hit leaves behind for the shadow stage
-struct ShadeOut { bool end; bool has_shadow; Ray shadow; F3 contrib; };
+struct ShadeOut { bool end; bool has_shadow; Ray shadow; F3 contrib; bool culled; };    // culled: an emitter sample whose term is exactly zero (no shadow ray)
 
 // ---- subsurface: where the path leaves the object (src/subsurface.cpp:106-150,199-249, src/pathMisIntegrator.cpp:86-100)
 __device__ __forceinline__ float ss_cdf(float r, float cs, float cd) {
@@ -1007,7 +1008,7 @@ __device__ __forceinline__ bool trace_masked(const DevScene &sc, const Ray &ray,
 }
 #define ND_PROBE_TRIES 4096      /* the reference retries without bound; a path that never finds its way out is dropped here */
 
-struct Counters { uint32_t closest, shadow, nodes, prims; };
+struct Counters { uint32_t closest, shadow, nodes, prims, culled; };
 
 // shade_hit in pieces, so that the wavefront pipeline can put a trace stage between drawing a subsurface probe and using its hit:
 //   shade_ctx     what every piece needs about the hit: surface record, local incident direction, albedo at the hit's uv
@@ -1024,7 +1025,7 @@ __device__ __forceinline__ void shade_ctx(const DevScene &sc, const Ray &ray, co
     if (EXT && shp.albedo_tex) cx.alb = tex_color(sc, sc.textures[shp.albedo_tex - 1], cx.sf.uv);
 }
 __device__ __forceinline__ bool shade_begin(const DevScene &sc, PathState &ps, Pcg32 &rng, const ShadeCtx &cx, ShadeOut &out) {
-    out.end = false; out.has_shadow = false; out.contrib = f3(0.f);
+    out.end = false; out.has_shadow = false; out.contrib = f3(0.f); out.culled = false;
     const Surface &sf = cx.sf;
     const NoriHipShape &shp = sc.shapes[sf.shape];
     if (shp.emitter >= 0) {                                               // :42-63
@@ -1089,6 +1090,11 @@ __device__ __forceinline__ void shade_finish(const DevScene &sc, PathState &ps, 
         float wem = lpdf / (lpdf + bpdf);
         float cosS = dot(normalized(lwi), normalized(osh.n));
         if (wem > 0) out.contrib = ((((ps.t * wem) * liLoc) * bsdf_eval(shp, alb, wi_l, wo_l)) * fabsf(cosS)) * (float) lights;
+        // The reference asks for visibility first and multiplies afterwards (src/pathMisIntegrator.cpp:125-143).  When the term is
+        // exactly zero - the light behind the surface's horizon (eval = 0), the emitter facing away (liLoc = 0), zero throughput -
+        // the answer cannot change Li (x + 0 = x in every rounding mode; a NaN term is not zero and keeps its ray), so the ray is
+        // not traced.  Counted apart (NoriHipStats::shadow_rays_culled), never as a ray in Mrays/s.
+        if (sc.cull_zero && out.contrib.x == 0.f && out.contrib.y == 0.f && out.contrib.z == 0.f) { out.has_shadow = false; out.culled = true; }
     }
     if (!wo_valid || is_zero(f)) { out.end = true; return; }
     ps.ray.d = next_dir; ps.ray.o = op; ps.ray.mint = 1e-3f; ps.ray.maxt = ND_INF;
@@ -1128,7 +1134,7 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
 template <bool EXT = true>
 __device__ __forceinline__ void shade_resume(const DevScene &sc, PathState &ps, Pcg32 &rng, const Ray &ray0, const Hit &hit0, Ray probe, Hit ph, int tries,
                                              ShadeOut &out, Counters *ctr) {
-    out.end = false; out.has_shadow = false; out.contrib = f3(0.f);
+    out.end = false; out.has_shadow = false; out.contrib = f3(0.f); out.culled = false;
     ShadeCtx cx; shade_ctx<EXT>(sc, ray0, hit0, cx);
     bool found = ph.pos != 0xffffffffu;
     for (++tries; tries < ND_PROBE_TRIES && !found; ++tries) {
@@ -1150,6 +1156,7 @@ __device__ __forceinline__ bool path_bounce(const DevScene &sc, const NodesT &no
     if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) { ps.li = ps.li + env_miss<EXT>(sc, ps.ray.d, ps.t, ps.last_bsdf_pdf, ps.last_delta); return false; }
     ShadeOut so;
     shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
+    if (so.culled) ctr.culled++;
     if (so.has_shadow) {
         Hit sh_hit;
         ctr.shadow++;

@@ -51,7 +51,7 @@ struct DevBufs {
 // Every counter the kernels bump therefore sits on a line of its own, and the hot ones are striped over ND_STRIPES
 // lines that the reader sums.
 #define ND_STRIPES 32
-struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims, ext_rays, ext_nodes, ext_prims, ext_visits; unsigned long long prof[2][10]; };
+struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims, ext_rays, ext_nodes, ext_prims, ext_visits, culled; unsigned long long prof[2][10]; };
 __device__ __forceinline__ DevStats *my_stats(DevStats *stats) { return stats + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ND_STRIPES - 1)); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -273,8 +273,8 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
         }
     }
     // per-wave reduction of the counters, one set of atomics per wave on the wave's stripe
-    unsigned long long v[6] = {n_samples, ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
-    for (int k = 0; k < 6; ++k) {
+    unsigned long long v[7] = {n_samples, ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims, ctr.culled};
+    for (int k = 0; k < 7; ++k) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         v[k] = x;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
     if (lane == 0) {
         DevStats *st = my_stats(stats);
         atomicAdd(&st->samples, v[0]); atomicAdd(&st->closest, v[1]); atomicAdd(&st->shadow, v[2]);
-        atomicAdd(&st->invalid, v[3]); atomicAdd(&st->nodes, v[4]); atomicAdd(&st->prims, v[5]);
+        atomicAdd(&st->invalid, v[3]); atomicAdd(&st->nodes, v[4]); atomicAdd(&st->prims, v[5]); if (v[6]) atomicAdd(&st->culled, v[6]);
     }
 }
 #define ND_RENDER_KERNEL(W) \
@@ -428,7 +428,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     const unsigned long long padded_total = job.padded_total;
     const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
     const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
-    unsigned int n_invalid = 0, n_degenerate = 0;
+    unsigned int n_invalid = 0, n_degenerate = 0, n_culled = 0;
     const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
     if (threadIdx.x == 0) { l_regen = 0u; l_keep = 0u; }
     __syncthreads();
@@ -459,7 +459,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         Ray probe; probe.o = f3(ro.x, ro.y, ro.z); probe.mint = ro.w; probe.d = f3(rd.x, rd.y, rd.z); probe.maxt = rd.w;
                         Hit ph; ph.pos = h.x; ph.t = __uint_as_float(h.y); ph.u = __uint_as_float(h.z); ph.v = __uint_as_float(h.w);
                         Surface sp; surface_from_hit<EXT>(sc, probe, ph, sp, false);
-                        so.end = false; so.has_shadow = false; so.contrib = f3(0.f);
+                        so.end = false; so.has_shadow = false; so.contrib = f3(0.f); so.culled = false;
                         shade_finish<EXT>(sc, ps, rng, cx, sp.p, sp.sh, so);
                         shaded = true;
                     } else {
@@ -498,6 +498,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                     } else { shade_finish<EXT>(sc, ps, rng, cx, cx.sf.p, cx.sf.sh, so); shaded = true; }
                 }
                 if (shaded) {
+                    if (so.culled) n_culled++;
                     flags = PF_ACTIVE | (ps.last_delta ? PF_LAST_DELTA : 0u);
                     if (so.has_shadow) {
                         flags |= PF_SHADOW;
@@ -584,9 +585,9 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
             pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
         }
     }
-    unsigned long long v0 = n_samples, v1 = n_invalid, v2 = n_degenerate;
-    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); v2 += __shfl_down(v2, off, 64); }
-    if (lane == 0 && (v0 | v1 | v2)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); if (v2) atomicAdd(&st->shadow, v2); }
+    unsigned long long v0 = n_samples, v1 = n_invalid, v2 = n_degenerate, v3 = n_culled;
+    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); v2 += __shfl_down(v2, off, 64); v3 += __shfl_down(v3, off, 64); }
+    if (lane == 0 && (v0 | v1 | v2 | v3)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); if (v2) atomicAdd(&st->shadow, v2); if (v3) atomicAdd(&st->culled, v3); }
 }
 // built for several register budgets (waves per SIMD); the stage is bound by the latency of its dependent fetches
 #define ND_SHADE_KERNEL(W) \
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
     uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - LDS_DEPTH];
     LdsStack stk; stk.spill = stack_spill; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
-    Counters ctr = {0, 0, 0, 0}; unsigned int n_invalid = 0;
+    Counters ctr = {0, 0, 0, 0, 0}; unsigned int n_invalid = 0;
     bool alive = false; unsigned int slot = 0;
     PathState ps; Pcg32 rng; Hit hit; float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
     // EXT: a slot taken over between the two halves of a subsurface bounce (PF_PROBE): its first trip finishes that bounce
@@ -982,6 +983,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             ShadeOut so;
             if (EXT && resume) { const Ray ray0 = ps.ray; shade_resume<EXT>(sc, ps, rng, ray0, hit0, probe0, hit, tries0, so, &ctr); resume = false; }
             else shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
+            if (so.culled) ctr.culled++;
             if (so.has_shadow) {
                 Hit sh; ctr.shadow++;
                 if (!(WIDE == 8 ? trace8<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : WIDE ? trace4<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims) : trace<true>(sc, so.shadow, sh, stk, ctr.nodes, ctr.prims))) ps.li = ps.li + so.contrib;
@@ -998,11 +1000,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
     }
-    unsigned long long v[5] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims};
-    for (int k = 0; k < 5; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
-    if (lane == 0 && (v[0] | v[1] | v[2])) {
+    unsigned long long v[6] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims, ctr.culled};
+    for (int k = 0; k < 6; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
+    if (lane == 0 && (v[0] | v[1] | v[2] | v[5])) {
         DevStats *st = my_stats(stats);
-        atomicAdd(&st->closest, v[0]); atomicAdd(&st->shadow, v[1]); atomicAdd(&st->invalid, v[2]); atomicAdd(&st->nodes, v[3]); atomicAdd(&st->prims, v[4]);
+        atomicAdd(&st->closest, v[0]); atomicAdd(&st->shadow, v[1]); atomicAdd(&st->invalid, v[2]); atomicAdd(&st->nodes, v[3]); atomicAdd(&st->prims, v[4]); if (v[5]) atomicAdd(&st->culled, v[5]);
     }
 }
 
@@ -1216,6 +1218,7 @@ struct NoriHipContext {
     int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
     int mega_waves = 4;               // k_render variant: waves per SIMD (NORI_HIP_MEGA_WAVES = 3, 4, 5, 6 or 8)
+    bool cull_zero = true;            // NORI_HIP_CULL=0: every emitter sample gets its shadow ray, as in the reference, also when its term is exactly zero
     int align_leaves = -1;            // NORI_HIP_LBVH_ALIGN: 1 / 0 = device-built trees with leaves of at most two records place them so that no leaf straddles a
                                       // 128-byte line (two of every eight record positions stay empty) or in plain sorted order; -1 = from a million records on
     int any_far = -1;                 // NORI_HIP_ANYORDER=far / near: any-hit rays enter first the child whose box they reach last / first (four-box nodes; the answer
@@ -1310,6 +1313,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_WIDE")) { const int v = atoi(e); c->wide = v != 0; c->wide8 = v == 8 ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
+    if (const char *e = getenv("NORI_HIP_CULL")) c->cull_zero = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_LBVH_ALIGN")) c->align_leaves = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("NORI_HIP_XCD")) { int v = atoi(e); if (v >= 0 && v <= 255) c->xcd_chunks = v; }
     if (const char *e = getenv("NORI_HIP_DYN")) { int v = atoi(e); if (v >= 0 && v <= 90) c->dyn_pct = v; }
@@ -1581,7 +1585,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
     // a device-built tree has no reference child order to keep: the nearer child is entered first
     sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u; sc.nodes8 = ctx->d_nodes8;
-    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; {
+    sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.cull_zero = ctx->cull_zero ? 1 : 0; {
         const size_t tree_b = (size_t) (ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
         const bool far = ctx->any_far >= 0 ? ctx->any_far != 0 : tree_b > ((size_t) 192 << 20);
         sc.ordered = ((ctx->ordered || device_build) ? 1 : 0) | (ctx->any_near ? 2 : 0) | (far ? 4 : 0);
@@ -2087,7 +2091,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     HIPCHK(hipMemcpy(stripes.data(), ctx->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
     DevStats ds; std::memset(&ds, 0, sizeof(ds));
     for (const DevStats &t : stripes) {
-        ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims; ds.ext_visits += t.ext_visits;
+        ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims; ds.ext_visits += t.ext_visits; ds.culled += t.culled;
         ds.samples += t.samples; ds.closest += t.closest; ds.shadow += t.shadow; ds.invalid += t.invalid; ds.nodes += t.nodes; ds.prims += t.prims;
         for (int k = 0; k < 2; ++k) for (int j = 0; j < 10; ++j) ds.prof[k][j] += t.prof[k][j];
     }
@@ -2098,7 +2102,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     ctx->fold_ext_events();
     ctx->stats.extend_ms = ctx->ext_ms_acc; ctx->stats.extend_launches = ctx->ext_launches;
     ctx->stats.extend_rays = ds.ext_rays; ctx->stats.extend_boxes = ds.ext_nodes; ctx->stats.extend_prims = ds.ext_prims;
-    ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width;
+    ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width; ctx->stats.shadow_rays_culled = ds.culled;
     if (ctx->profile) {
         static const char *names[10] = {"trips", "box_runs", "box_lanes", "prim_runs", "prim_lanes", "pop_runs", "pop_lanes", "refill_runs", "retired", "busy_lanes"};
         for (int k = 0; k < 2; ++k) {

@@ -37,7 +37,7 @@ class Stats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("invalid_samples", C.c_uint64),
                 ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint64), ("render_ms", C.c_double),
                 ("extend_ms", C.c_double), ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("extend_boxes", C.c_uint64),
-                ("extend_prims", C.c_uint64), ("extend_visits", C.c_uint64), ("extend_width", C.c_uint64)]
+                ("extend_prims", C.c_uint64), ("extend_visits", C.c_uint64), ("extend_width", C.c_uint64), ("shadow_rays_culled", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("lmin", "<f4", 3), ("lmax", "<f4", 3), ("rmin", "<f4", 3), ("rmax", "<f4", 3), ("left", "<u4"), ("right", "<u4"),

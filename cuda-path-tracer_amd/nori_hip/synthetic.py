@@ -69,7 +69,10 @@ def c4_meshes(n_side):
         out.append((k, v, fi, None))
     for li, (cx, cz) in enumerate([(-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5)]):
         s = 0.15
-        v, fi = _quad([[cx - s, 1.98, cz - s], [cx - s, 1.98, cz + s], [cx + s, 1.98, cz + s], [cx + s, 1.98, cz - s]])
+        # wound so that the geometric normal (p1 - p0) x (p2 - p0) points DOWN: area emitters are one-sided (src/arealight.cpp:41-54).
+        # (Until round 2 the quads were wound the other way round and lit only the ceiling 2 cm above them: every emitter sample
+        # taken from below evaluated to zero and the scene was lit by the ceiling's reflection alone.)
+        v, fi = _quad([[cx - s, 1.98, cz - s], [cx + s, 1.98, cz - s], [cx + s, 1.98, cz + s], [cx - s, 1.98, cz + s]])
         out.append(("light%d" % li, v, fi, (15.0, 15.0, 15.0)))
     return out
 

@@ -183,6 +183,8 @@ typedef struct NoriHipStats {
     uint64_t extend_rays, extend_boxes, extend_prims;   /* work of those launches */
     uint64_t extend_visits;        /* node fetches of those launches (four- and eight-box trace stages; 0 for the two-box walk, which fetches extend_boxes / 2) */
     uint64_t extend_width;         /* boxes per node the trace stage of the last render walked: 2, 4, or 8 (quantised boxes) */
+    uint64_t shadow_rays_culled;   /* emitter samples whose term was exactly zero and whose shadow ray was therefore not traced (NORI_HIP_CULL=0: none); the
+                                      reference traces them (src/pathMisIntegrator.cpp:125): shadow_rays + shadow_rays_culled is its shadow-ray count */
 } NoriHipStats;
 
 typedef struct NoriHipContext NoriHipContext;

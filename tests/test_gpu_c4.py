@@ -71,7 +71,7 @@ def test_c4_reduced_hits_and_li_against_oracle_with_the_reference_order_tree(c4_
     rel = np.abs(img.mean((0, 1)) - o.bitmap().mean((0, 1))) / o.bitmap().mean((0, 1))
     assert rel.max() < 2e-3, rel
     s = ctx.stats()
-    assert abs(s["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"] and abs(s["shadow_rays"] - ost["shadow"]) < 0.01 * ost["shadow"]
+    assert abs(s["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"] and abs(s["shadow_rays"] + s["shadow_rays_culled"] - ost["shadow"]) < 0.01 * ost["shadow"]
     hs.close()
 
 

@@ -119,7 +119,7 @@ def test_bench_scene_image_matches_oracle_at_matched_streams(loaded):
     assert close.mean() > 0.95, close.mean()
     st = ctx.stats()
     assert st["camera_samples"] == W * H * spp
-    assert abs(st["closest_rays"] - ost["closest"]) < 2e-3 * ost["closest"] and abs(st["shadow_rays"] - ost["shadow"]) < 2e-3 * ost["shadow"]
+    assert abs(st["closest_rays"] - ost["closest"]) < 2e-3 * ost["closest"] and abs(st["shadow_rays"] + st["shadow_rays_culled"] - ost["shadow"]) < 2e-3 * ost["shadow"]
 
 
 def test_li_on_reference_test_scenes_and_their_ttests(loaded):
@@ -164,7 +164,7 @@ def test_render_matches_oracle_image_at_matched_spp(loaded):
     st = ctx.stats()
     assert st["camera_samples"] == W * H * spp
     assert abs(st["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"]
-    assert abs(st["shadow_rays"] - ost["shadow"]) < 0.01 * ost["shadow"]
+    assert abs(st["shadow_rays"] + st["shadow_rays_culled"] - ost["shadow"]) < 0.01 * ost["shadow"]
 
 
 def test_spp_slices_and_tiles_accumulate_to_the_same_film(loaded):
@@ -352,7 +352,7 @@ def test_subsurface_render_against_oracle(loaded):
     assert rel.max() < 2e-3, rel
     st = ctx.stats()
     assert abs(st["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"]
-    assert abs(st["shadow_rays"] - ost["shadow"]) < 0.01 * ost["shadow"]
+    assert abs(st["shadow_rays"] + st["shadow_rays_culled"] - ost["shadow"]) < 0.01 * ost["shadow"]
 
 
 def test_filter_pass_matches_oracle(loaded):
@@ -526,7 +526,7 @@ def test_baseline_config0_image_against_oracle_and_the_reference_binary(loaded):
     close = np.abs(img - oimg).max(2) <= 1e-3 + 1e-2 * oimg.max(2)
     assert close.mean() > 0.95, close.mean()
     assert st["camera_samples"] == W * H * spp
-    assert abs(st["closest_rays"] - ost["closest"]) < 2e-3 * ost["closest"] and abs(st["shadow_rays"] - ost["shadow"]) < 2e-3 * ost["shadow"]
+    assert abs(st["closest_rays"] - ost["closest"]) < 2e-3 * ost["closest"] and abs(st["shadow_rays"] + st["shadow_rays_culled"] - ost["shadow"]) < 2e-3 * ost["shadow"]
 
 
 @pytest.mark.parametrize("name", ["cbox", "table", "dragon", "cbox_subsurface", "texture_bump", "cbox/8", "table/8", "dragon/8"])
