@@ -309,6 +309,8 @@ def main():
                    "bvh": ("device-built, %.1f ms, %d nodes, depth %d" % (bi["build_ms"], bi["n_used"], bi["depth"])) if bvh == "device" else "host SAH (reference order), %d 64-byte nodes" % info["wide_nodes"]},
         "mrays_per_s": round(rays_job / dt / 1e6, 2),
         "rays_per_sample": round(rays / (samples_per_step if not tiles else max(1, samples_per_step // world)), 3),
+        # emitter samples whose term was exactly zero get no shadow ray; they are in neither figure above
+        "culled_shadow_rays_per_sample": round(st["shadow_rays_culled"] / args.steps / (samples_per_step if not tiles else max(1, samples_per_step // world)), 3),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "valu_issue_busy": issue,

@@ -272,6 +272,41 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
     assert stats[0]["camera_samples"] == W * H * spp and stats[0]["iterations"] > 10
 
 
+@pytest.mark.parametrize("name", ["table_microfacet", "dragon", "cbox_subsurface"])
+def test_zero_term_cull_changes_no_radiance(name):
+    """An emitter sample whose term is exactly zero gets no shadow ray (NORI_HIP_CULL=0 traces it as the reference
+    does).  Per-sample Li is bit-identical either way, the film of a render too up to the order of its atomics, and the rays
+    not traced are counted apart: traced + culled is the shadow-ray count of the uncut run."""
+    W, H, spp = 72, 54, 4
+    xml = os.path.join(SCENES, SCENE_XML[name])
+    res = {}
+    for cull in ("0", "1"):
+        for pipe in ("wavefront", "mega"):
+            env = {"NORI_HIP_CULL": cull, "NORI_HIP_PIPELINE": pipe}
+            os.environ.update(env)
+            try:
+                hs = NH.HostScene(xml, W, H, spp)
+                ctx = hs.preprocess()
+            finally:
+                for k in env:
+                    del os.environ[k]
+            n = 6000
+            rng = np.random.default_rng(5)
+            rays = ctx.camera_rays((rng.random((n, 2)) * [W, H]).astype(np.float32))
+            li = ctx.li_samples(np.arange(n, dtype=np.uint64), np.full(n, 3, np.uint64), rays=rays)
+            ctx.reset_stats(); ctx.clear_film(); ctx.render(0, spp)
+            res[cull, pipe] = (li, ctx.read_film(), ctx.stats())
+            hs.close()
+    li0, f0, st0 = res["0", "wavefront"]
+    assert st0["shadow_rays_culled"] == 0
+    for key, (li, f, st) in res.items():
+        assert np.array_equal(li.view(np.uint32), li0.view(np.uint32)), key           # bit for bit, NaN patterns included
+        assert np.array_equal(f[:, :, 3], f0[:, :, 3]) and np.allclose(f, f0, rtol=1e-4, atol=1e-5), key
+        assert st["shadow_rays"] + st["shadow_rays_culled"] == st0["shadow_rays"] and st["closest_rays"] == st0["closest_rays"], key
+        assert (st["shadow_rays_culled"] > 0) == (key[0] == "1"), key
+    assert res["1", "wavefront"][2]["shadow_rays_culled"] > 0.03 * st0["shadow_rays"]
+
+
 def test_scene_whose_tree_is_one_leaf_through_every_schedule():
     """test-furnace.xml: 12 triangles in one leaf, so the root reference is that leaf and no box step ever runs (the
     speculative trace stage takes the leaf's entry distance from the ray's start, not from a box step).  One pixel, many
