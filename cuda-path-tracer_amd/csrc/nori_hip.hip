@@ -915,8 +915,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE8_W
 // stage launch per bounce would be mostly launch latency.  Persistent waves run the surviving paths of the live
 // list to their end, one bounce per loop trip (shade -> shadow -> extend in registers); wave w of W takes the
 // 64-entry batches w, w+W, ... and a lane whose path has ended takes the next entry of the wave's batch.
-template <bool EXT, int WIDE = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
+// WAVES: waves per SIMD the kernel is built for.  With four-box nodes the fused bounce wants ≈ 170 registers: at four waves (128) it
+// spills 78 of them, at three one.  Three is 1-2 % faster on the scenes that live in the caches (cbox 25.5 -> 24.9 ms, subsurface 92.0 ->
+// 90.4), four on the 10 M-triangle scene (367 against 373 ms: there the fourth wave hides more HBM latency than the spills cost).
+template <bool EXT, int WIDE = 0, int WAVES = 4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
     __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
     const unsigned int n = CN_LIVE(cnt);
     const unsigned int lane = threadIdx.x & 63u;
@@ -1961,10 +1964,13 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             if (n_upper == 0) break;
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
-                const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * 4u)));
-                if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                const unsigned fin_waves = (wide && !big_tree) ? 3u : 4u;
+                const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * fin_waves)));
+                if (ctx->ext && wide && !big_tree) hipLaunchKernelGGL((k_finish<true, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide8) hipLaunchKernelGGL((k_finish<false, 8>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (wide && !big_tree) hipLaunchKernelGGL((k_finish<false, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide) hipLaunchKernelGGL((k_finish<false, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
