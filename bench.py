@@ -81,13 +81,13 @@ def cpu_baseline(w, args):
     import oracle_lib as O
     threads = min(16, os.cpu_count() or 1)
     if w["xml"] is None:
-        # C4: the reference's ingest is text OBJ + a one-thread SAH build, minutes for 10 M triangles.  The bounded sample is
-        # the same generator at a tenth of the triangles (same box, lights, camera), written as OBJ + XML and loaded by the
-        # oracle as the reference would load it, rendered at reduced size.  Fewer triangles make the CPU's rays cheaper
-        # (a shallower tree), so this baseline errs in the CPU's favour.
+        # C4: the same mesh (all 10 M triangles unless --cpu-c4-side says otherwise), written as OBJ + XML and loaded by the oracle
+        # as the reference would load it (text parse + a one-thread SAH build: about a minute, reported apart), rendered at a
+        # reduced image size: the bounded sample is fewer pixels and samples per pixel of the same scene through the same camera (about 20 s
+        # on the GPU box's 16 host threads).
         import tempfile
         from nori_hip import synthetic
-        side, cw, ch, spp = args.cpu_c4_side, 256, 256, args.cpu_spp or 16
+        side, cw, ch, spp = args.cpu_c4_side or w["n_side"], 256, 256, args.cpu_spp or 8
         with tempfile.TemporaryDirectory() as d:
             t0 = time.time()
             xml = synthetic.write_c4(d, side, cw, ch, spp)
@@ -98,8 +98,8 @@ def cpu_baseline(w, args):
         sec, st = o.render(0, spp, mode=0, threads=threads)
         n = cw * ch * spp
         return {"value": round(n / sec / 1e6, 5), "unit": "Msamples/s", "cores": threads, "kind": "port",
-                "sample": "the same generator at n_side=%d (%d triangles instead of %d), %dx%d, %d spp (%.1f s), reference block-stream mode" % (
-                    side, o.info()["prims"], 2 * w["n_side"] ** 2 + 18, cw, ch, spp, sec),
+                "sample": "the same scene (%d of %d triangles), %dx%d instead of %dx%d pixels, %d spp (%.1f s), reference block-stream mode" % (
+                    o.info()["prims"], 2 * w["n_side"] ** 2 + 18, cw, ch, w["width"], w["height"], spp, sec),
                 "mrays_per_s": round((st["closest"] + st["shadow"]) / sec / 1e6, 4),
                 "boxes_tested_per_ray": round(st["nodes"] / max(1, st["closest"] + st["shadow"]), 1),
                 "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "obj_write_s": round(write_s, 2), "scene_load_and_bvh_build_s": round(load_s, 2)}
@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the workload's)")
     ap.add_argument("--bvh", default="", choices=["", "host", "device"], help="default: device for c4, host (the reference's tree and order) otherwise")
     ap.add_argument("--cpu-spp", type=int, default=0)
-    ap.add_argument("--cpu-c4-side", type=int, default=707)
+    ap.add_argument("--cpu-c4-side", type=int, default=0, help="c4 cpu_baseline: quads per side of the height field (default: the workload's own, 2236)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cbox measurement that the c4 run reports beside its own")
     ap.add_argument("--c4-side", type=int, default=0)
