@@ -669,7 +669,11 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
     // a position in that deal: round b / n_waves of wave b % n_waves (static part), or entry d % per_q of queue d / per_q.
     const unsigned int x_k = (box2_lanes >> 20) & 0xffu;
     const bool xmap = KIND == TK_BOTH && order != nullptr && x_k != 0u && (gridDim.x & 7u) == 0u;
-    const unsigned int x_wx = n_waves >> 3, x_cb = xmap ? (nb_pool + 8u * x_k - 1u) / (8u * x_k) : 0u;       // waves per XCD, batches of one kind per chunk
+    const unsigned int x_wx = n_waves >> 3;                                                                    // waves per XCD
+    unsigned int x_cb = xmap ? (nb_pool + 8u * x_k - 1u) / (8u * x_k) : 0u;                                   // batches of one kind per chunk
+    // (a wave's positions are x_wx apart: when that is a multiple of a chunk's 2 x_cb positions, or divides them, a wave would see the
+    // same part of every chunk - shadow batches only, or extend batches only, which cost differently - so the chunk is made one longer)
+    if (xmap && (x_wx % (2u * x_cb) == 0u || (2u * x_cb) % x_wx == 0u)) x_cb += 1u;
     const unsigned int x_w = (blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6);                       // this wave among its XCD's
     if (xmap) n_batches = ((2u * x_k * x_cb + x_wx - 1u) / x_wx) * n_waves;
     // The last dyn_pct percent of the rounds are not dealt statically: their batches [n_static, n_batches) sit in eight
