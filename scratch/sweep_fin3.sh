@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out; rm -f gpurun_out/sweep_fin3.txt
+for w in cbox table; do for f in 0 262144 524288 1500000 2097152; do
+  echo "W=$w FINISH=$f" >> gpurun_out/sweep_fin3.txt
+  NORI_HIP_FINISH=$f timeout -k 10 120 python bench.py --workload $w --no-cpu --steps 5 >> gpurun_out/sweep_fin3.txt 2>&1 || exit 1
+done; done

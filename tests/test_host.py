@@ -285,3 +285,28 @@ def test_exr_writer_follows_the_openexr_layout(tmp_path):
         out[y] = planes[::-1].T                                               # B, G, R planes -> r, g, b
     assert off + 8 + 33 * 12 == len(b)
     assert np.array_equal(out, img)
+
+
+def test_synthetic_scene_is_closed_and_lit_from_above(tmp_path):
+    """nori_hip/synthetic.py (BASELINE config 4 at reduced size): walls face inwards, the four light quads face DOWN - area
+    emitters are one-sided (src/arealight.cpp:41-54); wound the other way round they light only the ceiling above them, which is
+    what the generator did until round 2 - and the oracle's emitter samples from the floor carry radiance."""
+    from nori_hip import synthetic
+    meshes = synthetic.c4_meshes(16)
+    assert sum(len(F) for _, _, F, _ in meshes) == 2 * 16 * 16 + 18
+    for name, V, F, rad in meshes:
+        n = np.cross(V[F[:, 1]] - V[F[:, 0]], V[F[:, 2]] - V[F[:, 0]])
+        c = V[F].mean(1)
+        if name == "heightfield":
+            assert (n[:, 1] > 0).all()                                      # the terrain faces up
+        elif rad is not None:
+            assert (n[:, 1] < 0).all() and (n[:, [0, 2]] == 0).all()        # lights face the terrain
+        else:
+            assert ((n * (np.array([0, 1, 0], np.float32) - c)).sum(1) > 0).all(), name     # walls and ceiling face the inside
+    xml = synthetic.write_c4(str(tmp_path), 16, 32, 32, 1)
+    o = O.OracleScene(xml, 32, 32, 1)
+    ys, xs = np.mgrid[0:32, 0:32]
+    rays = o.camera_rays(np.stack([xs.ravel() + 0.5, ys.ravel() + 0.5], 1).astype(np.float32))
+    n_ = len(rays)
+    li = o.li_rays(rays, np.arange(n_, dtype=np.uint64), np.zeros(n_, np.uint64))
+    assert (li.max(1) > 0).mean() > 0.5          # most one-sample paths see a light directly (NEE), not only through the ceiling
