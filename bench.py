@@ -243,6 +243,37 @@ def main():
         secondary = [{"workload": w2["name"], "value": round(n2 / dt2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt2 / steps2 * 1e3, 3),
                       "steps": steps2, "warmup": 1, "spp_per_gpu": w2["spp"], "bvh": "host SAH (reference order)"}]
         os.environ["NORI_HIP_BVH"] = bvh
+    # The same workload once more with every emitter sample's shadow ray traced (NORI_HIP_CULL=0), as the reference does it: the
+    # library drops the ray when the sample's term is exactly zero (same film bit for bit).  Reported beside the
+    # headline so that both numbers come from one run.
+    uncut = None
+    if args.workload == "c4" and not args.no_secondary:
+        os.environ["NORI_HIP_CULL"] = "0"
+        try:
+            hs3 = synthetic.make_c4(args.c4_side or w["n_side"], w["width"], w["height"], w["spp"])      # (a scene of its own: preprocess() replaces a scene's context)
+            ctx3 = hs3.preprocess(device=local)
+        finally:
+            del os.environ["NORI_HIP_CULL"]
+        film3 = film_tensor(ctx3, torch) if world > 1 else None
+        kw = dict(ctx=ctx3, film=film3)
+        step(0, False, **kw)
+        sync(ctx3)
+        ctx3.reset_stats()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k, False, **kw)
+        sync(ctx3)
+        dt3 = time.perf_counter() - t0
+        st3 = ctx3.stats()
+        if dist is not None:
+            t3 = torch.tensor([dt3], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            dt3 = float(t3.item())
+        n3 = samples_per_step * args.steps * (1 if tiles else world)
+        uncut = {"value": round(n3 / dt3 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                 "rays_per_sample": round((st3["closest_rays"] + st3["shadow_rays"]) / args.steps / (samples_per_step if not tiles else max(1, samples_per_step // world)), 3),
+                 "note": "NORI_HIP_CULL=0: every emitter sample's shadow ray traced, as in the reference"}
+        hs3.close()
     # dominant kernel: the trace stage (k_trace_pool) of the wavefront pipeline, timed by the library with
     # HIP events around every one of its launches on the context's stream; with NORI_HIP_PIPELINE=mega the single
     # persistent kernel (k_render_w4), timed the same way around its last launch
@@ -321,6 +352,8 @@ def main():
     }
     if secondary:
         out["secondary"] = secondary
+    if uncut:
+        out["without_zero_term_cull"] = uncut
     if do_filter or world > 1:
         out["phases_ms_per_step"] = {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()}
     if not args.no_cpu and world == 1:
