@@ -917,6 +917,75 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE8_W
     trace_pool_body<TK_BOTH, PROF, SPEC, 8>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
 }
 
+// The two rays of a bounce - next ray and shadow ray - of the up to 64 paths a wave of the tail kernel holds, traced by the wave
+// together.  Traced lane by lane (each lane its shadow ray, then its next ray) a bounce lasts as long as the wave's longest shadow
+// traversal plus its longest closest-hit traversal, and most lanes idle most of that time (k_finish: 18 % lane utilisation on the
+// 10 M-triangle scene).  Here the rays are staged in the wave's LDS, next rays first (they are the longer ones), and a lane that has
+// finished a ray takes the next one of the list, whoever it belongs to, as the lanes of the trace stage do; results go back to the
+// owners through LDS.  Every ray is traversed by one lane with the same steps in the same order as before, so hits, any-hit answers
+// and the counts of box and record tests do not change.  Four-box nodes only.
+#define TW_RAYS 128
+template <typename StackT>
+__device__ __forceinline__ void trace_wave4(const DevScene &sc, StackT &stk, float4 *w_o, float4 *w_d, unsigned int *w_meta, uint4 *w_hit, unsigned int *w_occ,
+                                            const bool want_sh, const Ray &sh, const bool want_ex, const Ray &ex, bool &occluded, bool &found, Hit &hit,
+                                            uint32_t &n_nodes, uint32_t &n_prims) {
+    const unsigned int lane = threadIdx.x & 63u;
+    const unsigned long long m_ex = __ballot(want_ex), m_sh = __ballot(want_sh);
+    const unsigned int n_ex = (unsigned int) __popcll(m_ex), n_total = n_ex + (unsigned int) __popcll(m_sh);
+    if (want_ex) {
+        const unsigned int r = __builtin_amdgcn_mbcnt_hi((unsigned int) (m_ex >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_ex, 0u));
+        w_o[r] = make_float4(ex.o.x, ex.o.y, ex.o.z, ex.mint); w_d[r] = make_float4(ex.d.x, ex.d.y, ex.d.z, ex.maxt); w_meta[r] = lane;
+    }
+    if (want_sh) {
+        const unsigned int r = n_ex + __builtin_amdgcn_mbcnt_hi((unsigned int) (m_sh >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) m_sh, 0u));
+        w_o[r] = make_float4(sh.o.x, sh.o.y, sh.o.z, sh.mint); w_d[r] = make_float4(sh.d.x, sh.d.y, sh.d.z, sh.maxt); w_meta[r] = lane | 0x100u;
+    }
+    w_hit[lane] = make_uint4(0xffffffffu, 0u, 0u, 0u); w_occ[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    unsigned int next = 0;                                               // wave-uniform: rays [next, n_total) wait in LDS
+    Trav<false> tv; tv.cur = ND_DONE; tv.sp = 0; tv.found = false; tv.special = false; tv.hit.pos = 0xffffffffu; tv.hit.t = tv.hit.u = tv.hit.v = 0.f;
+    tv.o = tv.d = tv.rcp = f3(0.f); tv.mint = tv.maxt = 0.f; tv.cur_near = 0.f;
+    bool have = false, any = false; unsigned int owner = 0;
+    for (;;) {
+        next = __builtin_amdgcn_readfirstlane(next);
+        const unsigned long long fin = __ballot(tv.done());
+        if (fin) {
+            if (have && tv.done()) {
+                if (any) { if (tv.found) w_occ[owner] = 1u; }
+                else if (tv.found) w_hit[owner] = make_uint4(tv.hit.pos, __float_as_uint(tv.hit.t), __float_as_uint(tv.hit.u), __float_as_uint(tv.hit.v));
+                have = false;
+            }
+            if (next < n_total) {
+                const unsigned int idx = next + __builtin_amdgcn_mbcnt_hi((unsigned int) (fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) fin, 0u));
+                if (tv.done() && idx < n_total) {
+                    const float4 o4 = w_o[idx], d4 = w_d[idx]; const unsigned int me = w_meta[idx];
+                    owner = me & 0xffu; any = (me & 0x100u) != 0u;
+                    Ray r; r.o = f3(o4.x, o4.y, o4.z); r.mint = o4.w; r.d = f3(d4.x, d4.y, d4.z); r.maxt = d4.w;
+                    uint32_t nb = 0;
+                    if (tv.begin(sc, r, nb)) tv.cur = sc.root4;
+                    n_nodes += nb; have = true;
+                }
+                next += (unsigned int) __popcll(fin);
+            } else if (fin == ~0ull) break;
+        }
+        const bool ord = (any && (sc.ordered & 2)) || (sc.ordered & 1), far = any && (sc.ordered & 4);
+        const unsigned long long m_in = __ballot(tv.at_inner());
+        if (m_in) {
+            const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step4_fast(sc.nodes4, stk, ord, sort, far); }
+            else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step4(sc.nodes4, stk, ord, far); else n_nodes += tv.box_step4_fast(sc.nodes4, stk, ord, true, far); }
+        }
+        const unsigned long long m_lf = __ballot(tv.at_leaf());
+        if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) { if (tv.at_leaf()) tv.prim_step(sc, n_prims, any); }
+        if (tv.at_pop()) tv.pop_step(stk);
+    }
+    __builtin_amdgcn_wave_barrier();
+    occluded = w_occ[lane] != 0u;
+    const uint4 h = w_hit[lane];
+    found = h.x != 0xffffffffu;
+    hit.pos = h.x; hit.t = __uint_as_float(h.y); hit.u = __uint_as_float(h.z); hit.v = __uint_as_float(h.w);
+}
+
 // Tail of a render call: once the work counter is exhausted the number of live paths decays geometrically, and a
 // stage launch per bounce would be mostly launch latency.  Persistent waves run the surviving paths of the live
 // list to their end, one bounce per loop trip (shade -> shadow -> extend in registers); wave w of W takes the
@@ -926,14 +995,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE8_W
 // 90.4), four on the 10 M-triangle scene (367 against 373 ms: there the fourth wave hides more HBM latency than the spills cost).
 template <bool EXT, int WIDE = 0, int WAVES = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
-    __shared__ uint2 lds_stack[4 * LDS_DEPTH * 64];
+    constexpr int FIN_DEPTH = WIDE == 4 ? 6 : LDS_DEPTH;               // stack entries per lane in LDS (the staged rays of trace_wave4 want room too)
+    __shared__ uint2 lds_stack[4 * FIN_DEPTH * 64];
+    // WIDE == 4: the rays of a bounce staged per wave, and their results (trace_wave4)
+    __shared__ float4 tw_o[WIDE == 4 ? 4 * TW_RAYS : 1], tw_d[WIDE == 4 ? 4 * TW_RAYS : 1];
+    __shared__ unsigned int tw_meta[WIDE == 4 ? 4 * TW_RAYS : 1], tw_occ[WIDE == 4 ? 4 * 64 : 1];
+    __shared__ uint4 tw_hit[WIDE == 4 ? 4 * 64 : 1];
     const unsigned int n = CN_LIVE(cnt);
     const unsigned int lane = threadIdx.x & 63u;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, n_batches = (n + 63u) >> 6;
     unsigned int batch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
     unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
-    uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - LDS_DEPTH];
-    LdsStack stk; stk.spill = stack_spill; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (LDS_DEPTH * 64) + lane;
+    uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - FIN_DEPTH];
+    LdsStackT<FIN_DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (FIN_DEPTH * 64) + lane;
     Counters ctr = {0, 0, 0, 0, 0}; unsigned int n_invalid = 0;
     bool alive = false; unsigned int slot = 0;
     PathState ps; Pcg32 rng; Hit hit; float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -987,7 +1061,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
             if (cursor >= end) { batch += n_waves; cursor = batch << 6; end = (cursor + 64u < n) ? cursor + 64u : n; }
         }
         if (__ballot(alive) == 0ull) { if (batch >= n_batches) break; else continue; }
-        if (alive) {
+        if (WIDE == 4) {
+            // one bounce: the hit is in registers; the wave traces its shadow rays and next rays together
+            ShadeOut so; so.end = true; so.has_shadow = false; so.culled = false; so.contrib = f3(0.f);
+            so.shadow.o = so.shadow.d = f3(0.f); so.shadow.mint = 0.f; so.shadow.maxt = -1.f;
+            if (alive) {
+                if (EXT && resume) { const Ray ray0 = ps.ray; shade_resume<EXT>(sc, ps, rng, ray0, hit0, probe0, hit, tries0, so, &ctr); resume = false; }
+                else shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
+                if (so.culled) ctr.culled++;
+                if (so.has_shadow) ctr.shadow++;
+                if (!so.end) ctr.closest++;
+            }
+            const bool want_sh = alive && so.has_shadow, want_ex = alive && !so.end;
+            bool occluded = false, found = false; Hit nh;
+            const unsigned int wv_ = threadIdx.x >> 6;
+            trace_wave4(sc, stk, tw_o + wv_ * TW_RAYS, tw_d + wv_ * TW_RAYS, tw_meta + wv_ * TW_RAYS, tw_hit + wv_ * 64, tw_occ + wv_ * 64,
+                        want_sh, so.shadow, want_ex, ps.ray, occluded, found, nh, ctr.nodes, ctr.prims);
+            if (alive) {
+                if (want_sh && !occluded) ps.li = ps.li + so.contrib;
+                bool go_on = want_ex && found;
+                if (go_on) hit = nh;
+                else if (want_ex) ps.li = ps.li + env_miss<EXT>(sc, ps.ray.d, ps.t, ps.last_bsdf_pdf, ps.last_delta);
+                if (!go_on) {
+                    const unsigned int pxy = __float_as_uint(P.z);
+                    if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
+                    alive = false;
+                }
+            }
+        } else if (alive) {
             // one bounce: the hit is in registers
             ShadeOut so;
             if (EXT && resume) { const Ray ray0 = ps.ray; shade_resume<EXT>(sc, ps, rng, ray0, hit0, probe0, hit, tries0, so, &ctr); resume = false; }
