@@ -1323,6 +1323,7 @@ struct NoriHipContext {
     int pipeline = 1;                 // 1 = wavefront stages, 0 = single persistent kernel (k_render)
     bool pipeline_forced = false;     // NORI_HIP_PIPELINE was given; otherwise EXT scenes take the single kernel (measured faster: the
                                       // probe rays and image lookups of their shading are per-lane work the stages cannot batch)
+    int finish_waves = 0;             // NORI_HIP_FINISH_WAVES: 3 or 4 = which build of the tail kernel runs (0: three on scenes that live in the caches, four beyond)
     unsigned int finish_below = 0;    // live paths below which k_finish takes over; 0 = a quarter of the pool (NORI_HIP_FINISH)
     int shade_waves = 4;              // k_shade variant: waves per SIMD (NORI_HIP_SHADE_WAVES = 3, 4, 5, 6 or 8)
     int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
@@ -1430,6 +1431,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
     if (const char *e = getenv("NORI_HIP_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
+    if (const char *e = getenv("NORI_HIP_FINISH_WAVES")) { int v = atoi(e); if (v == 3 || v == 4) c->finish_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
@@ -2071,13 +2073,14 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             if (n_upper == 0) break;
             if (n_upper < finish_below) {
                 // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
-                const unsigned fin_waves = (wide && !big_tree) ? 3u : 4u;
+                const bool fin3 = wide && (ctx->finish_waves ? ctx->finish_waves == 3 : !big_tree);            // the tail kernel built for three waves per SIMD (see k_finish)
+                const unsigned fin_waves = fin3 ? 3u : 4u;
                 const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * fin_waves)));
-                if (ctx->ext && wide && !big_tree) hipLaunchKernelGGL((k_finish<true, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                if (ctx->ext && wide && fin3) hipLaunchKernelGGL((k_finish<true, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide8) hipLaunchKernelGGL((k_finish<false, 8>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (wide && !big_tree) hipLaunchKernelGGL((k_finish<false, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (wide && fin3) hipLaunchKernelGGL((k_finish<false, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide) hipLaunchKernelGGL((k_finish<false, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 HIPCHK(hipGetLastError());
