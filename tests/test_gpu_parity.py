@@ -231,6 +231,10 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="0"),               # ... dealt round-robin instead of by XCD
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="3", NORI_HIP_POOL="4096"),     # 24 chunks of 2-3 batches, positions past the end
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="255", NORI_HIP_DYN="50", NORI_HIP_DYN_TRIES="8", NORI_HIP_POOL="9000"),   # more chunks than batches; half from the queues
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_TRACE_BPC="4", NORI_HIP_XCD="1", NORI_HIP_POOL="24576"),   # a chunk as long as the waves' stride
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_TRACE_THREADS="1024", NORI_HIP_XCD="5", NORI_HIP_DYN="0"),
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_FINISH="20000", NORI_HIP_FINISH_WAVES="4"),       # long tails through either build of the tail kernel
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_FINISH="20000", NORI_HIP_FINISH_WAVES="3", NORI_HIP_POOL="24576"),
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0"),                                 # trace stage over the 64-byte two-box nodes
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0", NORI_HIP_SPEC="0", NORI_HIP_POOL="4096")]
     # Any-hit rays normally enter the nearer child first (the answer does not depend on the order, the number of records tested
