@@ -1314,6 +1314,7 @@ struct NoriHipContext {
     unsigned int pool_slots = 0; Pool pool, pool_b; void *pool_mem = nullptr;     // pool_b: half the slots, for the compaction of the tail
     unsigned int pool_alloc = 0;      // slots the allocated pool holds
     unsigned int *d_sort = nullptr; size_t sort_temp_bytes = 0;   // keys | keys' | slot numbers | slot numbers' (pool_alloc each) | sort workspace
+    int sort_bits = 16;               // NORI_HIP_SORT_BITS: most significant bits of the 30-bit cell key the ray sort looks at (8 .. 30)
     int sort_rays = -1;               // NORI_HIP_SORT: 1 / 0 = order the rays before every trace launch or never; -1 = when the tree does not fit the caches
     bool compact = true;              // NORI_HIP_COMPACT=0: never pack the pool (the tail then sweeps dead slots until k_finish takes over)
     unsigned int *d_qlive = nullptr; WfCounters *d_cnt = nullptr;
@@ -1423,6 +1424,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("NORI_HIP_WIDE")) { const int v = atoi(e); c->wide = v != 0; c->wide8 = v == 8 ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
+    if (const char *e = getenv("NORI_HIP_SORT_BITS")) { int v = atoi(e); if (v >= 8 && v <= 30) c->sort_bits = v; }
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
     if (const char *e = getenv("NORI_HIP_CULL")) c->cull_zero = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_LBVH_ALIGN")) c->align_leaves = atoi(e) != 0 ? 1 : 0;
@@ -2033,7 +2035,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             if (wide && sort_rays) {
                 unsigned int *k0 = ctx->d_sort, *k1 = k0 + ctx->pool_alloc, *v0 = k1 + ctx->pool_alloc, *v1 = v0 + ctx->pool_alloc;
                 hipLaunchKernelGGL(k_ray_keys, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, k0, v0);
-                HIPCHK(lbvh::sort_pairs(ctx->stream, v1 + ctx->pool_alloc, ctx->sort_temp_bytes, k0, k1, v0, v1, P, 30));
+                // (the order only has to gather the rays of a region: the top 16 of the key's 30 bits do as well as all of them, in two radix passes instead of four)
+                HIPCHK(lbvh::sort_pairs(ctx->stream, v1 + ctx->pool_alloc, ctx->sort_temp_bytes, k0, k1, v0, v1, P, 30, 30 - ctx->sort_bits));
                 order = v1;
             }
             if (ctx->merge_trace) {

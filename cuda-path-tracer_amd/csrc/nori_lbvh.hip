@@ -565,8 +565,8 @@ size_t sort_pairs_temp_bytes(uint32_t n) {
     (void) hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr, (uint32_t *) nullptr, (int) n, 0, 32, (hipStream_t) nullptr);
     return bytes;
 }
-hipError_t sort_pairs(hipStream_t stream, void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, int end_bit) {
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int) n, 0, end_bit, stream);
+hipError_t sort_pairs(hipStream_t stream, void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, int end_bit, int begin_bit) {
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int) n, begin_bit, end_bit, stream);
 }
 
 } // namespace lbvh
