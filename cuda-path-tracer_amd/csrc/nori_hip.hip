@@ -389,6 +389,16 @@ __device__ __forceinline__ unsigned int spread10(unsigned int x) {
     x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u;
     return x;
 }
+#define ND_NO_KEY 0x3fffffffu            /* a slot without a ray: sorts last */
+__device__ __forceinline__ unsigned int cell_key(const DevScene &sc, float px, float py, float pz) {
+    const float ex = sc.root_max[0] - sc.root_min[0], ey = sc.root_max[1] - sc.root_min[1], ez = sc.root_max[2] - sc.root_min[2];
+    const float qx = ex > 0.f ? (px - sc.root_min[0]) / ex : 0.f, qy = ey > 0.f ? (py - sc.root_min[1]) / ey : 0.f, qz = ez > 0.f ? (pz - sc.root_min[2]) / ez : 0.f;
+    const unsigned int ix = (unsigned int) fminf(fmaxf(qx * 1024.f, 0.f), 1023.f), iy = (unsigned int) fminf(fmaxf(qy * 1024.f, 0.f), 1023.f), iz = (unsigned int) fminf(fmaxf(qz * 1024.f, 0.f), 1023.f);
+    const unsigned int key = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
+    return key == ND_NO_KEY ? ND_NO_KEY - 1u : key;
+}
+__global__ void k_iota(unsigned int *ids, unsigned int n) { const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) ids[i] = i; }
+// (the shade stage writes the keys itself, from the rays it has in registers; this kernel is what it replaced and stays for NORI_HIP_KEYS=kernel)
 __global__ __launch_bounds__(256) void k_ray_keys(DevScene sc, Pool pool, unsigned int n_slots, unsigned int *keys, unsigned int *ids) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
@@ -398,11 +408,7 @@ __global__ __launch_bounds__(256) void k_ray_keys(DevScene sc, Pool pool, unsign
     if (ext || sh) {
         // the path vertex: the extend ray's origin, or (the path ends here) the far end of the shadow ray
         const float px = ext ? o.x : so.x + sd.w * sd.x, py = ext ? o.y : so.y + sd.w * sd.y, pz = ext ? o.z : so.z + sd.w * sd.z;
-        const float ex = sc.root_max[0] - sc.root_min[0], ey = sc.root_max[1] - sc.root_min[1], ez = sc.root_max[2] - sc.root_min[2];
-        const float qx = ex > 0.f ? (px - sc.root_min[0]) / ex : 0.f, qy = ey > 0.f ? (py - sc.root_min[1]) / ey : 0.f, qz = ez > 0.f ? (pz - sc.root_min[2]) / ez : 0.f;
-        const unsigned int ix = (unsigned int) fminf(fmaxf(qx * 1024.f, 0.f), 1023.f), iy = (unsigned int) fminf(fmaxf(qy * 1024.f, 0.f), 1023.f), iz = (unsigned int) fminf(fmaxf(qz * 1024.f, 0.f), 1023.f);
-        key = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
-        if (key == 0x3fffffffu) key = 0x3ffffffeu;
+        key = cell_key(sc, px, py, pz);
     }
     keys[i] = key; ids[i] = i;
 }
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256) void k_ray_keys(DevScene sc, Pool pool, unsign
 enum { SL_IDLE = 0x8000u };
 template <bool EXT>
 __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, const RenderJob &job, float4 *film, unsigned int *q_live,
-                                           WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
+                                           WfCounters *cnt, unsigned long long *work_counter, DevStats *stats, unsigned int *keys) {
     extern __shared__ unsigned short run_list[];                            // per_block entries
     __shared__ unsigned int l_regen, l_keep;
     __shared__ unsigned long long b_work; __shared__ unsigned int b_live;
@@ -435,6 +441,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
         const unsigned int slot = i0 + lane;
         bool regen = false, keep = false, idle = false;
+        F3 kp = f3(0.f); bool kvalid = false;            // where the slot's path stands after this bounce (the ray sort's key), if it has a ray
         if (slot < hi) {
             const float4 L = pool.li[slot]; const uint4 h = pool.hit[slot]; const float4 P = pool.pix[slot];
             const float4 ro = pool.ray_o[slot], rd = pool.ray_d[slot], T = pool.thr[slot]; const uint4 R = pool.rng[slot];
@@ -469,6 +476,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                             Ray probe; ss_probe_ray(sc, cx, rng, probe);
                             pool.ray_o[slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, probe.mint);
                             pool.ray_d[slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, probe.maxt);
+                            kp = probe.o; kvalid = true;
                             pool.hit[slot] = make_uint4(ND_PROBE_MARK, cx.sf.shape, 0u, 0u);
                             pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                             pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float((flags & (PF_ACTIVE | PF_LAST_DELTA | PF_PROBE)) | (tries << PF_TRIES_SHIFT)));
@@ -490,6 +498,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         pool.sv_o[slot] = ro; pool.sv_d[slot] = rd; pool.sv_h[slot] = h;
                         pool.ray_o[slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, probe.mint);
                         pool.ray_d[slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, probe.maxt);
+                        kp = probe.o; kvalid = true;
                         pool.hit[slot] = make_uint4(ND_PROBE_MARK, cx.sf.shape, 0u, 0u);
                         pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
                         pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
@@ -518,6 +527,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         ended = false;
                         pool.ray_o[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.mint);
                         pool.ray_d[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.ray.maxt);
+                        kp = ps.ray.o; kvalid = true;
                         pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
                         pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
@@ -525,6 +535,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         // the path ends, but its last NEE term is still pending: it stays one more iteration without a next ray
                         ended = false;
                         pool.ray_d[slot] = no_ray;
+                        if (new_shadow) { kp = so.shadow.o + so.shadow.d * so.shadow.maxt; kvalid = true; }      // the path ends here: the far end of its last shadow ray
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags | PF_ENDING));
                     }
                 }
@@ -534,6 +545,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                     if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
                 } else { regen = false; keep = true; }
             }
+            if (keys) keys[slot] = (keep && kvalid) ? cell_key(sc, kp.x, kp.y, kp.z) : ND_NO_KEY;      // (a slot that starts a new path gets its key in pass B)
         }
         const unsigned long long m_r = __ballot(regen), m_k = __ballot(keep);
         unsigned int pr = 0, pk = 0;
@@ -569,6 +581,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                 Ray r0; camera_ray(sc, pixel_sample, r0);
                 pool.ray_o[slot] = make_float4(r0.o.x, r0.o.y, r0.o.z, r0.mint);
                 pool.ray_d[slot] = make_float4(r0.d.x, r0.d.y, r0.d.z, r0.maxt);
+                if (keys) keys[slot] = cell_key(sc, r0.o.x, r0.o.y, r0.o.z);
                 pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
                 pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                 pool.pix[slot] = make_float4(pixel_sample.x, pixel_sample.y, __uint_as_float((unsigned int) px | ((unsigned int) py << 16)), 0.f);
@@ -593,15 +606,15 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
 #define ND_SHADE_KERNEL(W) \
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) \
 void k_shade_w##W(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, WfCounters *cnt, \
-                  unsigned long long *work_counter, DevStats *stats) { shade_body<false>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats); }
+                  unsigned long long *work_counter, DevStats *stats, unsigned int *keys) { shade_body<false>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
 ND_SHADE_KERNEL(3)
 ND_SHADE_KERNEL(4)
 ND_SHADE_KERNEL(5)
 ND_SHADE_KERNEL(6)
 ND_SHADE_KERNEL(8)
 __global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
-                                                   WfCounters *cnt, unsigned long long *work_counter, DevStats *stats) {
-    shade_body<true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats); }
+                                                   WfCounters *cnt, unsigned long long *work_counter, DevStats *stats, unsigned int *keys) {
+    shade_body<true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
 
 // Trace stage: persistent waves over the pool.  Wave w of W takes the 64-slot batches w, w+W, w+2W, ... (a static,
 // interleaved share: no shared counter) for the first 85 % of the rounds; the rest comes from eight queues, see below.  Rays reach the lanes through a small pipeline, so that the HBM latency of
@@ -1314,6 +1327,7 @@ struct NoriHipContext {
     unsigned int pool_slots = 0; Pool pool, pool_b; void *pool_mem = nullptr;     // pool_b: half the slots, for the compaction of the tail
     unsigned int pool_alloc = 0;      // slots the allocated pool holds
     unsigned int *d_sort = nullptr; size_t sort_temp_bytes = 0;   // keys | keys' | slot numbers | slot numbers' (pool_alloc each) | sort workspace
+    bool fused_keys = true;           // NORI_HIP_KEYS=kernel: the sort keys come from a kernel of their own (k_ray_keys) instead of from the shade stage
     int sort_bits = 16;               // NORI_HIP_SORT_BITS: most significant bits of the 30-bit cell key the ray sort looks at (8 .. 30)
     int sort_rays = -1;               // NORI_HIP_SORT: 1 / 0 = order the rays before every trace launch or never; -1 = when the tree does not fit the caches
     bool compact = true;              // NORI_HIP_COMPACT=0: never pack the pool (the tail then sweeps dead slots until k_finish takes over)
@@ -1424,6 +1438,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("NORI_HIP_WIDE")) { const int v = atoi(e); c->wide = v != 0; c->wide8 = v == 8 ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
+    if (const char *e = getenv("NORI_HIP_KEYS")) c->fused_keys = std::string(e) != "kernel";
     if (const char *e = getenv("NORI_HIP_SORT_BITS")) { int v = atoi(e); if (v >= 8 && v <= 30) c->sort_bits = v; }
     if (const char *e = getenv("NORI_HIP_DYN_TRIES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->dyn_tries = v; }
     if (const char *e = getenv("NORI_HIP_CULL")) c->cull_zero = atoi(e) != 0;
@@ -1970,6 +1985,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         unsigned int *srt = nullptr; const size_t tb = (lbvh::sort_pairs_temp_bytes((uint32_t) PA) + 255) & ~(size_t) 255;
         HIPCHK(guard.get(srt, PA * 16 + tb));
         ctx->d_sort = srt; ctx->sort_temp_bytes = tb;
+        hipLaunchKernelGGL(k_iota, dim3((unsigned) ((PA + 255) / 256)), dim3(256), 0, ctx->stream, srt + 2 * PA, (unsigned int) PA);
         guard.owned.clear();                                                   // all succeeded: the context owns them now
         ctx->pool_mem = mem; ctx->d_qlive = ql; ctx->pool_alloc = (unsigned int) PA;
         auto carve = [](Pool &pl, float4 *base, size_t n) {
@@ -2016,13 +2032,14 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     size_grids(P);
     Pool pools[2] = {ctx->pool, ctx->pool_b}; int pi = 0;                      // the pool in use; P shrinks with every compaction
     const int SW = ctx->shade_waves;
-    void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, WfCounters *, unsigned long long *, DevStats *) =
+    void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, WfCounters *, unsigned long long *, DevStats *, unsigned int *) =
         ctx->ext ? k_shade_ext : SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     uint64_t it = 0;
     for (;; ++it) {
         hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
-        hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), shade_lds, ctx->stream, ctx->sc, pools[pi], P, job, ctx->d_film, ctx->d_qlive, c, ctx->d_counter, ctx->d_stats);
+        hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), shade_lds, ctx->stream, ctx->sc, pools[pi], P, job, ctx->d_film, ctx->d_qlive, c, ctx->d_counter, ctx->d_stats,
+                           (wide && sort_rays && ctx->fused_keys) ? ctx->d_sort : (unsigned int *) nullptr);
         {
             if (ctx->ext_used + 2 > ctx->ext_ev.size()) {
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
@@ -2034,7 +2051,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             const unsigned int *order = nullptr;
             if (wide && sort_rays) {
                 unsigned int *k0 = ctx->d_sort, *k1 = k0 + ctx->pool_alloc, *v0 = k1 + ctx->pool_alloc, *v1 = v0 + ctx->pool_alloc;
-                hipLaunchKernelGGL(k_ray_keys, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, k0, v0);
+                // (keys: written by the shade stage; slot numbers: 0, 1, 2, ... since the pool was allocated)
+                if (!ctx->fused_keys) hipLaunchKernelGGL(k_ray_keys, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, k0, v0);
                 // (the order only has to gather the rays of a region: the top 16 of the key's 30 bits do as well as all of them, in two radix passes instead of four)
                 HIPCHK(lbvh::sort_pairs(ctx->stream, v1 + ctx->pool_alloc, ctx->sort_temp_bytes, k0, k1, v0, v1, P, 30, 30 - ctx->sort_bits));
                 order = v1;
