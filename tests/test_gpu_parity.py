@@ -229,6 +229,7 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
     configs += [dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1"),                                 # rays ordered by the cell of their path vertex
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_POOL="1000", NORI_HIP_FINISH="1"),
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="0"),               # ... dealt round-robin instead of by XCD
+                dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_KEYS="kernel", NORI_HIP_SORT_BITS="30"),   # keys from a kernel of their own, every bit sorted
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="3", NORI_HIP_POOL="4096"),     # 24 chunks of 2-3 batches, positions past the end
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_XCD="255", NORI_HIP_DYN="50", NORI_HIP_DYN_TRIES="8", NORI_HIP_POOL="9000"),   # more chunks than batches; half from the queues
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_SORT="1", NORI_HIP_TRACE_BPC="4", NORI_HIP_XCD="1", NORI_HIP_POOL="24576"),   # a chunk as long as the waves' stride
