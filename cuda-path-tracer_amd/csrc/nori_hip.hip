@@ -1462,7 +1462,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_THR")) {          // "box,prim,refill" lane thresholds, for tuning
         int a, b, d; if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3 && a >= 1 && b >= 1 && d >= 1 && a <= 64 && b <= 64 && d <= 64) { c->thr_box = a; c->thr_prim = b; c->thr_refill = d; }
     }
-    c->pool_slots = 0;                 // 0: sized per render call (a quarter of the call's paths, between 1M and 8M slots)
+    c->pool_slots = 0;                 // 0: sized per render call (three eighths of the call's paths, half for big trees, between 1M and 8M slots)
     if (const char *e = getenv("NORI_HIP_POOL")) { long v = atol(e); if (v >= 64 && v <= (1l << 26)) c->pool_slots = (unsigned int) v; }
     HIPCHK(hipMalloc((void **) &c->d_cnt, sizeof(WfCounters)));
     HIPCHK(hipHostMalloc((void **) &c->h_ring, 4 * sizeof(unsigned int), hipHostMallocDefault));
@@ -1961,17 +1961,18 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         return NORI_HIP_OK;
     }
     // ---- wavefront stages over a pool of path slots
-    // The pool is sized for the call (a quarter of its paths, between 1 M and 8 M slots, or NORI_HIP_POOL) and allocated when a
+    // The pool is sized for the call (three eighths of its paths - cbox 512 x 512 x 64: 25.0 ms with a quarter, 24.1 with three eighths, 24.5
+    // with a half - between 1 M and 8 M slots, or NORI_HIP_POOL) and allocated when a
     // call needs more slots than the context holds; pool, half-size pool and live list are committed to the context together.
     // "big tree": nodes and records against the Infinity Cache (256 MiB).  Beyond it the trace stage waits for HBM lines instead of
     // issuing, and a few defaults change with that (measured on the 10 M-triangle workload): rays are ordered before every trace
-    // launch, no speculative traversal, no second box step per trip, and half instead of a quarter of the call's paths in the pool
+    // launch, no speculative traversal, no second box step per trip, and half instead of three eighths of the call's paths in the pool
     // (fewer, larger launches: the stage's ramp-up and drain are paid less often).
     const size_t tree_bytes = (size_t) (ctx->n_nodes8 ? (size_t) ctx->n_nodes8 * 128 : ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
     const bool big_tree = tree_bytes > ((size_t) 192 << 20);
     const unsigned int pool_cap = ctx->pool_slots ? ctx->pool_slots : (1u << 23);
     unsigned int P = pool_cap;
-    if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, (job.total / (big_tree ? 2 : 4) + 65535) & ~65535ull));
+    if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, ((big_tree ? job.total / 2 : ctx->has_ss ? job.total / 4 : job.total * 3 / 8) + 65535) & ~65535ull));     // (scenes with subsurface shapes: 13 pool arrays instead of 10, a quarter measured better: 89.8 against 92.7 ms)
     if ((unsigned long long) P > ((job.total + 63) / 64) * 64) P = (unsigned int) (((job.total + 63) / 64) * 64);
     if (!ctx->pool_mem || ctx->pool_alloc < P) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
