@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void k_ray_keys(DevScene sc, Pool pool, unsign
 // The host sizes the grid so that a run has at most SHADE_RUN_MAX slots.
 #define SHADE_RUN_MAX 16384u
 enum { SL_IDLE = 0x8000u };
-template <bool EXT>
+// KEYS: the stage also writes the ray sort's key of every slot (the cell its path stands in after this bounce)
+template <bool EXT, bool KEYS = false>
 __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, const RenderJob &job, float4 *film, unsigned int *q_live,
                                            WfCounters *cnt, unsigned long long *work_counter, DevStats *stats, unsigned int *keys) {
     extern __shared__ unsigned short run_list[];                            // per_block entries
@@ -476,7 +477,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                             Ray probe; ss_probe_ray(sc, cx, rng, probe);
                             pool.ray_o[slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, probe.mint);
                             pool.ray_d[slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, probe.maxt);
-                            kp = probe.o; kvalid = true;
+                            if (KEYS) { kp = probe.o; kvalid = true; }
                             pool.hit[slot] = make_uint4(ND_PROBE_MARK, cx.sf.shape, 0u, 0u);
                             pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                             pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float((flags & (PF_ACTIVE | PF_LAST_DELTA | PF_PROBE)) | (tries << PF_TRIES_SHIFT)));
@@ -498,7 +499,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         pool.sv_o[slot] = ro; pool.sv_d[slot] = rd; pool.sv_h[slot] = h;
                         pool.ray_o[slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, probe.mint);
                         pool.ray_d[slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, probe.maxt);
-                        kp = probe.o; kvalid = true;
+                        if (KEYS) { kp = probe.o; kvalid = true; }
                         pool.hit[slot] = make_uint4(ND_PROBE_MARK, cx.sf.shape, 0u, 0u);
                         pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
                         pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
@@ -527,7 +528,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         ended = false;
                         pool.ray_o[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.mint);
                         pool.ray_d[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, ps.ray.maxt);
-                        kp = ps.ray.o; kvalid = true;
+                        if (KEYS) { kp = ps.ray.o; kvalid = true; }
                         pool.thr[slot] = make_float4(ps.t.x, ps.t.y, ps.t.z, ps.last_bsdf_pdf);
                         pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags));
@@ -535,7 +536,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                         // the path ends, but its last NEE term is still pending: it stays one more iteration without a next ray
                         ended = false;
                         pool.ray_d[slot] = no_ray;
-                        if (new_shadow) { kp = so.shadow.o + so.shadow.d * so.shadow.maxt; kvalid = true; }      // the path ends here: the far end of its last shadow ray
+                        if (KEYS && new_shadow) { kp = so.shadow.o + so.shadow.d * so.shadow.maxt; kvalid = true; }      // the path ends here: the far end of its last shadow ray
                         pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float(flags | PF_ENDING));
                     }
                 }
@@ -545,7 +546,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                     if (!film_put(sc, film, f2(P.x, P.y), (int) (pxy & 0xffffu), (int) (pxy >> 16), ps.li)) n_invalid++;
                 } else { regen = false; keep = true; }
             }
-            if (keys) keys[slot] = (keep && kvalid) ? cell_key(sc, kp.x, kp.y, kp.z) : ND_NO_KEY;      // (a slot that starts a new path gets its key in pass B)
+            if (KEYS) keys[slot] = (keep && kvalid) ? cell_key(sc, kp.x, kp.y, kp.z) : ND_NO_KEY;      // (a slot that starts a new path gets its key in pass B)
         }
         const unsigned long long m_r = __ballot(regen), m_k = __ballot(keep);
         unsigned int pr = 0, pk = 0;
@@ -581,7 +582,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                 Ray r0; camera_ray(sc, pixel_sample, r0);
                 pool.ray_o[slot] = make_float4(r0.o.x, r0.o.y, r0.o.z, r0.mint);
                 pool.ray_d[slot] = make_float4(r0.d.x, r0.d.y, r0.d.z, r0.maxt);
-                if (keys) keys[slot] = cell_key(sc, r0.o.x, r0.o.y, r0.o.z);
+                if (KEYS) keys[slot] = cell_key(sc, r0.o.x, r0.o.y, r0.o.z);
                 pool.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
                 pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                 pool.pix[slot] = make_float4(pixel_sample.x, pixel_sample.y, __uint_as_float((unsigned int) px | ((unsigned int) py << 16)), 0.f);
@@ -615,6 +616,13 @@ ND_SHADE_KERNEL(8)
 __global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
                                                    WfCounters *cnt, unsigned long long *work_counter, DevStats *stats, unsigned int *keys) {
     shade_body<true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
+// ... writing the ray sort's keys too (the default variants only)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_shade_w4_keys(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, WfCounters *cnt,
+                     unsigned long long *work_counter, DevStats *stats, unsigned int *keys) { shade_body<false, true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
+__global__ __launch_bounds__(256) void k_shade_ext_keys(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
+                                                        WfCounters *cnt, unsigned long long *work_counter, DevStats *stats, unsigned int *keys) {
+    shade_body<true, true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
 
 // Trace stage: persistent waves over the pool.  Wave w of W takes the 64-slot batches w, w+W, w+2W, ... (a static,
 // interleaved share: no shared counter) for the first 85 % of the rounds; the rest comes from eight queues, see below.  Rays reach the lanes through a small pipeline, so that the HBM latency of
@@ -2035,12 +2043,15 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const int SW = ctx->shade_waves;
     void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, WfCounters *, unsigned long long *, DevStats *, unsigned int *) =
         ctx->ext ? k_shade_ext : SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
+    // the shade stage writes the sort keys itself where a variant for that exists (the default ones); otherwise k_ray_keys does
+    const bool fused_keys = wide && sort_rays && ctx->fused_keys && (ctx->ext || SW == 4);
+    if (fused_keys) shade_kern = ctx->ext ? k_shade_ext_keys : k_shade_w4_keys;
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     uint64_t it = 0;
     for (;; ++it) {
         hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
         hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), shade_lds, ctx->stream, ctx->sc, pools[pi], P, job, ctx->d_film, ctx->d_qlive, c, ctx->d_counter, ctx->d_stats,
-                           (wide && sort_rays && ctx->fused_keys) ? ctx->d_sort : (unsigned int *) nullptr);
+                           fused_keys ? ctx->d_sort : (unsigned int *) nullptr);
         {
             if (ctx->ext_used + 2 > ctx->ext_ev.size()) {
                 if (ctx->ext_ev.size() >= 4096) { int rc2 = ctx->fold_ext_events(); if (rc2) return rc2; }
@@ -2053,7 +2064,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             if (wide && sort_rays) {
                 unsigned int *k0 = ctx->d_sort, *k1 = k0 + ctx->pool_alloc, *v0 = k1 + ctx->pool_alloc, *v1 = v0 + ctx->pool_alloc;
                 // (keys: written by the shade stage; slot numbers: 0, 1, 2, ... since the pool was allocated)
-                if (!ctx->fused_keys) hipLaunchKernelGGL(k_ray_keys, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, k0, v0);
+                if (!fused_keys) hipLaunchKernelGGL(k_ray_keys, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->sc, pools[pi], P, k0, v0);
                 // (the order only has to gather the rays of a region: the top 16 of the key's 30 bits do as well as all of them, in two radix passes instead of four)
                 HIPCHK(lbvh::sort_pairs(ctx->stream, v1 + ctx->pool_alloc, ctx->sort_temp_bytes, k0, k1, v0, v1, P, 30, 30 - ctx->sort_bits));
                 order = v1;
