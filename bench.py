@@ -65,6 +65,155 @@ def film_tensor(ctx, torch):
     return torch.as_tensor(_Film(), device="cuda")
 
 
+def committed_traffic(args, kname, bvh):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload, tree and kernel (they cannot run
+    inside this process): profiles/r03_<workload>_traffic.json, else round 2's; (None, None) when none matches"""
+    if args.spp or args.c4_side:
+        return None, None
+    for rnd in ("r03", "r02"):
+        tpath = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, args.workload))
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == kname and tj.get("bvh", bvh) == bvh:
+                return int(tj["traffic_bytes_per_launch"]), tj.get("valu_issue_busy")
+    return None, None
+
+
+def roofline_dict(kname, achieved, kernel_ms, traffic, issue, note, extra):
+    """`achieved` / `frac`: ALGORITHMIC bytes per launch over the launch's duration, against the HBM peak (SURVEY 8d's definition: work
+    retired, caches included).  `traffic_gbs` / `traffic_frac`: the bytes the memory side actually moved per launch (PMC counters of the
+    committed profile) over the same duration - how busy the HBM pins are.  Where the two differ, the difference is reuse in L2."""
+    d = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "achieved_algorithmic": round(achieved, 1), "traffic": traffic,
+         "traffic_gbs": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic is not None else None),
+         "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic is not None else None),
+         "valu_issue_busy": issue, "note": note, "kernel_ms": round(kernel_ms, 4)}
+    d.update(extra)
+    return d
+
+
+def load_workload(args, NH, synthetic):
+    """(workload dict, bvh mode, host scene, load seconds) for args.workload; NORI_HIP_BVH is left set to the mode"""
+    w = dict(WORKLOADS[args.workload])
+    if args.spp:
+        w["spp"] = args.spp
+    bvh = args.bvh or os.environ.get("NORI_HIP_BVH") or ("device" if w["xml"] is None else "host")
+    os.environ["NORI_HIP_BVH"] = bvh
+    t0 = time.time()
+    if w["xml"] is None:
+        hs = synthetic.make_c4(args.c4_side or w["n_side"], w["width"], w["height"], w["spp"])
+    else:
+        hs = NH.HostScene(os.path.join(ROOT, w["xml"]), w["width"], w["height"], w["spp"])
+    return w, bvh, hs, time.time() - t0
+
+
+def group_mode(args):
+    """--driver group: the product's own multi-GPU path.  One process, nori_hip_group_render over min(--gpus, devices present)
+    devices: every member renders its spp slice (weak scaling: --gpus x spp samples per pixel in all) or its 32-row bands
+    (--partition tiles, strong), the films are summed in place by one RCCL all-reduce inside the call, and for the c5 workload
+    the filter pass follows on member 0.  Same JSON line as the default mode; phases_ms_per_step.reduce is the device time of the
+    all-reduce (nori_hip_group_reduce_ms)."""
+    import nori_hip as NH
+    from nori_hip import synthetic
+    w, bvh, hs, load_s = load_workload(args, NH, synthetic)
+    n_dev = max(1, min(args.gpus, NH.device_count()))
+    g = NH.Group(list(range(n_dev)))
+    g.upload(hs.flatten(), build_on_device=(bvh == "device"))
+    c0 = g.context(0)
+    tiles = args.partition == "tiles"
+    spp_total = w["spp"] if tiles else w["spp"] * n_dev
+    part = NH.PARTITION_TILES if tiles else NH.PARTITION_SPP
+    do_filter = bool(w.get("filter"))
+    phase = {"render": 0.0, "reduce": 0.0, "filter": 0.0}
+
+    def step(timed):
+        g.clear_film()
+        t_a = time.perf_counter()
+        g.render(0, spp_total, part)                      # returns when every member holds the summed film
+        t_b = time.perf_counter()
+        if do_filter:
+            c0.filter(**FILTER_PARAMS)
+        t_c = time.perf_counter()
+        if timed:
+            red = g.reduce_ms() * 1e-3
+            phase["render"] += (t_b - t_a) - red; phase["reduce"] += red; phase["filter"] += t_c - t_b
+
+    for _ in range(args.warmup):
+        step(False)
+    for i in range(n_dev):
+        g.context(i).synchronize(); g.context(i).reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    for i in range(n_dev):
+        g.context(i).synchronize()
+    dt = time.perf_counter() - t0
+    sts = [g.context(i).stats() for i in range(n_dev)]
+    st = sts[0]
+    rays_job = float(sum(x["closest_rays"] + x["shadow_rays"] for x in sts))
+    samples = w["width"] * w["height"] * spp_total * args.steps
+    launches = max(1, st["extend_launches"])
+    kernel_ms = st["extend_ms"] / launches
+    alg_bytes = (32.0 * st["extend_boxes"] + 40.0 * st["extend_prims"] + 60.0 * st["extend_rays"]) / launches
+    kname = c0.trace_kernel_name()
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if st["extend_launches"] else 0.0
+    traffic, issue = committed_traffic(args, kname, bvh) if n_dev == 1 else (None, None)
+    info = hs.info()
+    out = {
+        "metric": "Msamples/s (path_mis, whole node)", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s",
+        "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if w["xml"] is None else "reference scene files (scenes/)",
+        "config": {"workload": w["name"], "width": w["width"], "height": w["height"], "spp_per_gpu": w["spp"], "triangles": info["prims"],
+                   "driver": "group: one process, nori_hip_group_render over %d device(s) (%d asked for)" % (n_dev, args.gpus),
+                   "partition": ("32-row bands, one render call per member" if tiles else "spp slices") + ", in-place RCCL all-reduce of the fp32 film",
+                   "scene_load_s": round(load_s, 2), "bvh": "device-built" if bvh == "device" else "host SAH (reference order)"},
+        "mrays_per_s": round(rays_job / dt / 1e6, 2),
+        "roofline": roofline_dict(kname, achieved, kernel_ms, traffic, issue,
+                                  "member 0's trace stage; algorithmic bytes per SURVEY 8d, counted by the kernel itself", {"algorithmic_bytes_per_launch": int(alg_bytes)}),
+        "phases_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()},
+    }
+    print(json.dumps(out))
+    g.close(); hs.close()
+
+
+def as_rank_mode(args):
+    """--as-rank N: what strong scaling over N GPUs would look like, measured on one.  The whole workload is timed, then the share
+    of every rank r of an N-way split - its interleaved 32-row bands in one nori_hip_render_tiles call, and (if spp >= N) its spp
+    slice of the whole image - is rendered alone on this GPU.  On a node the ranks run side by side, so a step lasts as long as the
+    slowest share plus the film reduce (1.5 ms for 133 MB): predicted efficiency = whole / (N x slowest share)."""
+    import nori_hip as NH
+    from nori_hip import synthetic
+    from nori_hip.partition import split_spp, tile_bands
+    w, bvh, hs, load_s = load_workload(args, NH, synthetic)
+    ctx = hs.preprocess(device=0)
+    N, W, H, spp = args.as_rank, w["width"], w["height"], w["spp"]
+
+    def timed(fn):
+        for _ in range(max(1, args.warmup)):
+            ctx.clear_film(); fn(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.clear_film(); fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / args.steps * 1e3
+
+    whole = timed(lambda: ctx.render(0, spp))
+    out = {"mode": "as-rank", "workload": w["name"], "n_ranks": N, "steps": args.steps, "ms_whole": round(whole, 3), "ms_ideal_share": round(whole / N, 3), "partitions": {}}
+    shares = []
+    for r in range(N):
+        bands = [(0, y0, W, y1) for y0, y1 in tile_bands(r, N, H)]
+        shares.append(timed(lambda: ctx.render_tiles(0, spp, bands)) if bands else 0.0)
+    out["partitions"]["tiles"] = {"ms_per_rank": [round(x, 3) for x in shares], "ms_slowest": round(max(shares), 3),
+                                  "predicted_efficiency": round(whole / (N * max(shares)), 4)}
+    if spp >= N:
+        shares = [timed(lambda: ctx.render(b, e)) for b, e in split_spp(spp, N)]
+        out["partitions"]["spp"] = {"ms_per_rank": [round(x, 3) for x in shares], "ms_slowest": round(max(shares), 3),
+                                    "predicted_efficiency": round(whole / (N * max(shares)), 4)}
+    print(json.dumps(out))
+    hs.close()
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -135,7 +284,17 @@ def main():
     ap.add_argument("--c4-side", type=int, default=0)
     ap.add_argument("--partition", default="spp", choices=["spp", "tiles"],
                     help="spp: every rank renders its own spp slice of the whole image (weak scaling, default); tiles: the ranks share one image by interleaved 32-row bands (strong scaling)")
+    ap.add_argument("--driver", default="ranks", choices=["ranks", "group"],
+                    help="ranks: one process per GPU, torch.distributed all-reduce (the launch contract of this file, default); group: ONE process drives --gpus devices "
+                         "through nori_hip_group_* (what the path_mis plugin's `devices` property and the CLI use; fewer devices present: as many as there are)")
+    ap.add_argument("--as-rank", type=int, default=0, metavar="N",
+                    help="strong-scaling prediction on one GPU: render every rank's share of an N-way split of the workload (tiles, and spp slices if spp >= N), "
+                         "one after the other, and print the slowest share against whole/N")
     args = ap.parse_args()
+    if args.as_rank:
+        return as_rank_mode(args)
+    if args.driver == "group":
+        return group_mode(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -317,13 +476,7 @@ def main():
     # HBM bytes per launch of the same kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, scratch/pmc.sh; the doubling
     # holds for scattered reads too: scratch/fetchprobe.hip, profiles/r02_fetchprobe.txt), which cannot run inside this
     # process: the committed measurement of this workload, tree and kernel, if there is one
-    traffic, issue = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % args.workload)
-    if os.path.exists(tpath) and not args.spp and not args.c4_side:
-        tj = json.load(open(tpath))
-        if tj.get("kernel") == kname and tj.get("bvh", bvh) == bvh:
-            traffic = int(tj["traffic_bytes_per_launch"])
-            issue = tj.get("valu_issue_busy")
+    traffic, issue = committed_traffic(args, kname, bvh)
     if traffic is not None and traffic < 0.5 * alg_bytes:
         roof_note = ("algorithmic bytes (SURVEY 8d) count every box and record test at full size; on this scene the nodes and records stay in L1/L2 "
                      "(traffic = HBM bytes per launch from the committed PMC passes), so frac is not an HBM fraction here: what bounds the kernel is vector-ALU issue "
@@ -342,13 +495,10 @@ def main():
         "rays_per_sample": round(rays / (samples_per_step if not tiles else max(1, samples_per_step // world)), 3),
         # emitter samples whose term was exactly zero get no shadow ray; they are in neither figure above
         "culled_shadow_rays_per_sample": round(st["shadow_rays_culled"] / args.steps / (samples_per_step if not tiles else max(1, samples_per_step // world)), 3),
-        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "valu_issue_busy": issue,
-                     "note": roof_note,
-                     "kernel_ms": round(kernel_ms, 4), "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
+        "roofline": roofline_dict(kname, achieved, kernel_ms, traffic, issue, roof_note, extra={
+                     "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
                      "boxes_tested_per_ray": round(st["boxes_tested"] / max(1.0, rays_rank), 2), "prims_tested_per_ray": round(st["prims_tested"] / max(1.0, rays_rank), 2),
-                     "node_width": int(st["extend_width"]), "node_visits_per_ray": (round(st["extend_visits"] / max(1.0, st["extend_rays"]), 2) if wavefront else None)},
+                     "node_width": int(st["extend_width"]), "node_visits_per_ray": (round(st["extend_visits"] / max(1.0, st["extend_rays"]), 2) if wavefront else None)}),
     }
     if secondary:
         out["secondary"] = secondary

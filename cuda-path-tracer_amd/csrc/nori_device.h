@@ -1006,9 +1006,10 @@ __device__ __forceinline__ bool trace_masked(const DevScene &sc, const Ray &ray,
     hit = tv.hit;
     return tv.found;
 }
-#define ND_PROBE_TRIES 4096      /* the reference retries without bound; a path that never finds its way out is dropped here */
+#define ND_PROBE_TRIES 4096      /* the reference retries without bound; here a bounce that never finds its way out ends the path, which keeps (and splats) the
+                                    radiance gathered so far; counted in NoriHipStats::ss_paths_dropped */
 
-struct Counters { uint32_t closest, shadow, nodes, prims, culled; };
+struct Counters { uint32_t closest, shadow, nodes, prims, culled, dropped; };     // dropped: subsurface bounces that ran out of probes (ND_PROBE_TRIES)
 
 // shade_hit in pieces, so that the wavefront pipeline can put a trace stage between drawing a subsurface probe and using its hit:
 //   shade_ctx     what every piece needs about the hit: surface record, local incident direction, albedo at the hit's uv
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg
             if (ctr) { ctr->closest++; ctr->nodes += nn; ctr->prims += np; }
             if (found) { Surface so; surface_from_hit<EXT>(sc, probe, ph, so, false); op = so.p; osh = so.sh; }
         }
-        if (!found) { out.end = true; return; }
+        if (!found) { out.end = true; if (ctr) ctr->dropped++; return; }
     }
     shade_finish<EXT>(sc, ps, rng, cx, op, osh, out);
 }
@@ -1143,7 +1144,7 @@ __device__ __forceinline__ void shade_resume(const DevScene &sc, PathState &ps, 
         found = trace_masked(sc, probe, cx.sf.shape, ph, nn, np);
         if (ctr) { ctr->closest++; ctr->nodes += nn; ctr->prims += np; }
     }
-    if (!found) { out.end = true; return; }
+    if (!found) { out.end = true; if (ctr) ctr->dropped++; return; }
     Surface so; surface_from_hit<EXT>(sc, probe, ph, so, false);
     shade_finish<EXT>(sc, ps, rng, cx, so.p, so.sh, out);
 }

@@ -165,6 +165,30 @@ int nori_hip_group_reduce_films(NoriHipGroup *g) {
     return NORI_HIP_OK;
 }
 
+// The split of a group render as a pure function of (members, member, sample range, image height): see include/nori_hip.h.
+int nori_hip_group_plan(int n, int i, int spp_begin, int spp_end, int height, int partition, int *out_b, int *out_e, int *bands, int max_bands, int *out_n_bands) {
+    if (n < 1 || i < 0 || i >= n) return fail(NORI_HIP_EINVAL, "nori_hip_group_plan: no member " + std::to_string(i) + " in a group of " + std::to_string(n));
+    if (spp_begin < 0 || spp_end <= spp_begin) return fail(NORI_HIP_EINVAL, "empty sample range");
+    if (height < 1) return fail(NORI_HIP_EINVAL, "bad image height");
+    if (partition != NORI_HIP_PARTITION_SPP && partition != NORI_HIP_PARTITION_TILES) return fail(NORI_HIP_EINVAL, "unknown partition");
+    if (!out_b || !out_e || !out_n_bands) return fail(NORI_HIP_EINVAL, "null argument");
+    *out_n_bands = 0;
+    if (partition == NORI_HIP_PARTITION_SPP) {
+        // contiguous slices, the first (count mod n) one sample longer
+        const int total = spp_end - spp_begin, base = total / n, extra = total % n;
+        *out_b = spp_begin + i * base + std::min(i, extra);
+        *out_e = *out_b + base + (i < extra ? 1 : 0);
+        return NORI_HIP_OK;
+    }
+    // every n-th band of NORI_BLOCK_SIZE (32) rows, all samples
+    *out_b = spp_begin; *out_e = spp_end;
+    int k = 0;
+    for (long long y = 32ll * i; y < height; y += 32ll * n, ++k)
+        if (bands && k < max_bands) { bands[2 * k] = (int) y; bands[2 * k + 1] = (int) std::min<long long>(y + 32, height); }
+    *out_n_bands = k;
+    return NORI_HIP_OK;
+}
+
 int nori_hip_group_render(NoriHipGroup *g, int spp_begin, int spp_end, int partition) {
     if (!g) return fail(NORI_HIP_EINVAL, "null group");
     if (spp_begin < 0 || spp_end <= spp_begin) return fail(NORI_HIP_EINVAL, "empty sample range");
@@ -178,23 +202,32 @@ int nori_hip_group_render(NoriHipGroup *g, int spp_begin, int spp_end, int parti
         // After a group render every member holds the job's film.  What the films held before this call must enter the sum once:
         // it stays in member 0's film, the other members start from zero.
         if (i > 0) { int r0 = nori_hip_clear_film(g->ctx[i]); if (r0) return r0; }
+        int b = 0, e = 0, n_bands = 0;
+        const int max_bands = (H + 31) / 32;
+        std::vector<int> bands((size_t) 2 * max_bands);
+        int r1 = nori_hip_group_plan(n, (int) i, spp_begin, spp_end, H, partition, &b, &e, bands.data(), max_bands, &n_bands);
+        if (r1) return r1;
         if (partition == NORI_HIP_PARTITION_SPP) {
-            // member i takes samples [b, e): contiguous slices, the first (spp mod n) one sample longer
-            const int total = spp_end - spp_begin, base = total / n, extra = total % n;
-            const int b = spp_begin + (int) i * base + std::min<int>((int) i, extra), e = b + base + ((int) i < extra ? 1 : 0);
-            if (e <= b) return NORI_HIP_OK;
+            if (e <= b) return NORI_HIP_OK;                         // more members than samples: nothing for this one
             int r2 = nori_hip_render(g->ctx[i], 0, 0, W, H, b, e);
             return r2 ? r2 : nori_hip_synchronize(g->ctx[i]);
         }
-        // every n-th band of NORI_BLOCK_SIZE (32) rows, all samples, in one call
+        if (n_bands == 0) return NORI_HIP_OK;                      // more members than bands
         std::vector<int> tiles;
-        for (int y = 32 * (int) i; y < H; y += 32 * n) { tiles.push_back(0); tiles.push_back(y); tiles.push_back(W); tiles.push_back(std::min(y + 32, H)); }
-        if (tiles.empty()) return NORI_HIP_OK;
-        int r2 = nori_hip_render_tiles(g->ctx[i], tiles.data(), (int) (tiles.size() / 4), spp_begin, spp_end);
+        for (int k = 0; k < n_bands; ++k) { tiles.push_back(0); tiles.push_back(bands[2 * k]); tiles.push_back(W); tiles.push_back(bands[2 * k + 1]); }
+        int r2 = nori_hip_render_tiles(g->ctx[i], tiles.data(), n_bands, b, e);      // the member's bands in ONE pass
         return r2 ? r2 : nori_hip_synchronize(g->ctx[i]);
     });
-    if (rc) return rc;
-    return nori_hip_group_reduce_films(g);
+    if (rc == NORI_HIP_OK) rc = nori_hip_group_reduce_films(g);
+    if (rc) {
+        // A member failed: some members have dropped what they held, some have rendered a part of their share, and nothing was
+        // summed (or the sum itself failed half-way).  No film is the job's film any more; all are cleared so that a caller who
+        // goes on sees an empty film and not a plausible wrong one.  (include/nori_hip.h documents this.)
+        const std::string why = nori_hip_last_error();
+        for (NoriHipContext *c : g->ctx) { (void) nori_hip_clear_film(c); (void) nori_hip_synchronize(c); }
+        return fail(rc, why + " (the films of all group members were cleared)");
+    }
+    return NORI_HIP_OK;
 }
 
 int nori_hip_group_reduce_ms(NoriHipGroup *g, double *ms) { if (!g || !ms) return fail(NORI_HIP_EINVAL, "null argument"); *ms = g->reduce_ms; return NORI_HIP_OK; }

@@ -51,7 +51,7 @@ struct DevBufs {
 // Every counter the kernels bump therefore sits on a line of its own, and the hot ones are striped over ND_STRIPES
 // lines that the reader sums.
 #define ND_STRIPES 32
-struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims, ext_rays, ext_nodes, ext_prims, ext_visits, culled; unsigned long long prof[2][10]; };
+struct alignas(256) DevStats { unsigned long long samples, closest, shadow, invalid, nodes, prims, ext_rays, ext_nodes, ext_prims, ext_visits, culled, dropped; unsigned long long prof[2][10]; };
 __device__ __forceinline__ DevStats *my_stats(DevStats *stats) { return stats + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ND_STRIPES - 1)); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_li_samples(DevScene sc, size_t n, const
     else if (px) camera_ray(sc, f2((float) px[i] + j.x, (float) py[i] + j.y), ray);
     else camera_ray(sc, f2(j.x * (float) sc.cam.width, j.y * (float) sc.cam.height), ray);      // src/ttest.cpp:171-172
     PathState ps; path_init(ps, ray);
-    ScratchStack stk; Counters c = {0, 0, 0, 0};
+    ScratchStack stk; Counters c = {0, 0, 0, 0, 0, 0};
     GlobalNodes g; g.nodes = sc.nodes;
     if (KIND == NORI_HIP_INTEGRATOR_PATH_MATS) { while (path_bounce_mats<EXT>(sc, g, ps, rng, stk, c)) { } }
     else if (KIND == NORI_HIP_INTEGRATOR_DIRECT_MIS) path_direct_mis<EXT>(sc, g, ps, rng, stk, c);
@@ -227,7 +227,7 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
     nodes.cache = (lds_f4 *) dyn_lds + (MEGA_THREADS / 64) * (MEGA_DEPTH * 64 * 8 / 16);
     nodes.fill();
     __syncthreads();
-    Counters ctr = {0, 0, 0, 0};
+    Counters ctr = {0, 0, 0, 0, 0, 0};
     unsigned int n_samples = 0, n_invalid = 0;
     PathState ps; Pcg32 rng; F2 pixel_sample = f2(0.f, 0.f); int px = 0, py = 0;
     bool alive = false;
@@ -273,8 +273,8 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
         }
     }
     // per-wave reduction of the counters, one set of atomics per wave on the wave's stripe
-    unsigned long long v[7] = {n_samples, ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims, ctr.culled};
-    for (int k = 0; k < 7; ++k) {
+    unsigned long long v[8] = {n_samples, ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims, ctr.culled, ctr.dropped};
+    for (int k = 0; k < 8; ++k) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         v[k] = x;
@@ -283,6 +283,7 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
         DevStats *st = my_stats(stats);
         atomicAdd(&st->samples, v[0]); atomicAdd(&st->closest, v[1]); atomicAdd(&st->shadow, v[2]);
         atomicAdd(&st->invalid, v[3]); atomicAdd(&st->nodes, v[4]); atomicAdd(&st->prims, v[5]); if (v[6]) atomicAdd(&st->culled, v[6]);
+        if (v[7]) atomicAdd(&st->dropped, v[7]);
     }
 }
 #define ND_RENDER_KERNEL(W) \
@@ -435,7 +436,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     const unsigned long long padded_total = job.padded_total;
     const unsigned int per_block = (((n_slots + gridDim.x - 1) / gridDim.x) + 255u) & ~255u;
     const unsigned int lo = blockIdx.x * per_block, hi = (lo + per_block < n_slots) ? lo + per_block : n_slots;
-    unsigned int n_invalid = 0, n_degenerate = 0, n_culled = 0;
+    unsigned int n_invalid = 0, n_degenerate = 0, n_culled = 0, n_dropped = 0;
     const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
     if (threadIdx.x == 0) { l_regen = 0u; l_keep = 0u; }
     __syncthreads();
@@ -482,7 +483,7 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
                             pool.rng[slot] = make_uint4((unsigned int) rng.state, (unsigned int) (rng.state >> 32), (unsigned int) rng.inc, (unsigned int) (rng.inc >> 32));
                             pool.li[slot] = make_float4(ps.li.x, ps.li.y, ps.li.z, __uint_as_float((flags & (PF_ACTIVE | PF_LAST_DELTA | PF_PROBE)) | (tries << PF_TRIES_SHIFT)));
                             ended = false;
-                        }
+                        } else n_dropped++;                                          // every probe left the shape: the path ends with what it has (NoriHipStats::ss_paths_dropped)
                     }
                 } else if (EXT && !(flags & PF_ENDING) && h.x == 0xffffffffu) {
                     // the ray left the scene: the environment emitter, if there is one (the path ends either way)
@@ -599,9 +600,9 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
             pool.li[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
         }
     }
-    unsigned long long v0 = n_samples, v1 = n_invalid, v2 = n_degenerate, v3 = n_culled;
-    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); v2 += __shfl_down(v2, off, 64); v3 += __shfl_down(v3, off, 64); }
-    if (lane == 0 && (v0 | v1 | v2 | v3)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); if (v2) atomicAdd(&st->shadow, v2); if (v3) atomicAdd(&st->culled, v3); }
+    unsigned long long v0 = n_samples, v1 = n_invalid, v2 = n_degenerate, v3 = n_culled, v4 = n_dropped;
+    for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_down(v0, off, 64); v1 += __shfl_down(v1, off, 64); v2 += __shfl_down(v2, off, 64); v3 += __shfl_down(v3, off, 64); if (EXT) v4 += __shfl_down(v4, off, 64); }
+    if (lane == 0 && (v0 | v1 | v2 | v3 | v4)) { DevStats *st = my_stats(stats); atomicAdd(&st->samples, v0); atomicAdd(&st->invalid, v1); if (v2) atomicAdd(&st->shadow, v2); if (v3) atomicAdd(&st->culled, v3); if (v4) atomicAdd(&st->dropped, v4); }
 }
 // built for several register budgets (waves per SIMD); the stage is bound by the latency of its dependent fetches
 #define ND_SHADE_KERNEL(W) \
@@ -1029,7 +1030,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
     uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - FIN_DEPTH];
     LdsStackT<FIN_DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (FIN_DEPTH * 64) + lane;
-    Counters ctr = {0, 0, 0, 0, 0}; unsigned int n_invalid = 0;
+    Counters ctr = {0, 0, 0, 0, 0, 0}; unsigned int n_invalid = 0;
     bool alive = false; unsigned int slot = 0;
     PathState ps; Pcg32 rng; Hit hit; float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
     // EXT: a slot taken over between the two halves of a subsurface bounce (PF_PROBE): its first trip finishes that bounce
@@ -1131,11 +1132,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
             }
         }
     }
-    unsigned long long v[6] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims, ctr.culled};
-    for (int k = 0; k < 6; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
-    if (lane == 0 && (v[0] | v[1] | v[2] | v[5])) {
+    unsigned long long v[7] = {ctr.closest, ctr.shadow, n_invalid, ctr.nodes, ctr.prims, ctr.culled, ctr.dropped};
+    for (int k = 0; k < 7; ++k) { unsigned long long x = v[k]; for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64); v[k] = x; }
+    if (lane == 0 && (v[0] | v[1] | v[2] | v[5] | v[6])) {
         DevStats *st = my_stats(stats);
         atomicAdd(&st->closest, v[0]); atomicAdd(&st->shadow, v[1]); atomicAdd(&st->invalid, v[2]); atomicAdd(&st->nodes, v[3]); atomicAdd(&st->prims, v[4]); if (v[5]) atomicAdd(&st->culled, v[5]);
+        if (v[6]) atomicAdd(&st->dropped, v[6]);
     }
 }
 
@@ -1494,6 +1496,10 @@ static int create_impl(NoriHipContext *c, int device) {
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
+    // the filter kernels may use whatever LDS a workgroup can have (their tile grows with r + f): set once, here, so that the filter
+    // entry points - nori_hip_filter_noalloc in particular, which is meant for capture and tight loops - change no driver state
+    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans, hipFuncAttributeMaxDynamicSharedMemorySize, (int) std::min<size_t>(c->lds_bytes, 160 * 1024)));
+    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans_sep, hipFuncAttributeMaxDynamicSharedMemorySize, (int) std::min<size_t>(c->lds_bytes, 160 * 1024)));
     c->trace_lds_wide8 = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH_W8 * 64 * 8 + 64 * 52);
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide8));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide8));
@@ -1743,6 +1749,8 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         // the same lookup the integrator uses (scale, delta and filtering included), summed in double on the host
         const NoriHipTexture &t = d->textures[d->env.texture - 1];
         const uint32_t w = t.width, h = t.height; const size_t n = (size_t) w * h;
+        // (every failure from here on releases the scene that has just been uploaded: have_scene stays false, nothing stays attached)
+        struct Undo { NoriHipContext *c; bool armed = true; ~Undo() { if (armed) { c->free_scene(); c->sc.env.texture = 0u; c->sc.env_cdf = nullptr; c->sc.env_w = c->sc.env_h = 0u; } } } undo{ctx};
         if (n >= (1u << 28)) return fail(NORI_HIP_EINVAL, "environment image too large");
         sc.env_w = w; sc.env_h = h;
         DevBufs bufs; float *d_wt = nullptr;
@@ -1759,6 +1767,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         cdf[n] = 1.0f;
         if ((rc = upload(ctx->d_env_cdf, cdf.data(), n + 1))) return rc;
         sc.env_cdf = ctx->d_env_cdf;
+        undo.armed = false;
     }
     ctx->have_scene = true;
     return NORI_HIP_OK;
@@ -2183,19 +2192,18 @@ int nori_hip_filter(NoriHipContext *ctx, int r, int f, float sigma, float h, flo
     if (!out) return fail(NORI_HIP_EINVAL, "null buffer");
     if (r < 0 || f < 0 || !(sigma > 0) || !(h > 0)) return fail(NORI_HIP_EINVAL, "bad filter parameters");
     const int W = ctx->sc.cam.width, H = ctx->sc.cam.height, R = r + f;
+    const char *fenv = getenv("NORI_HIP_FILTER");
+    const bool direct_early = fenv && std::string(fenv) == "direct";
     size_t lds = ((size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 + (size_t) (2 * f + 1) * (2 * f + 1)) * sizeof(float);
-    if (lds > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile (r + f <= 48)");
+    if (direct_early && lds > std::min<size_t>(ctx->lds_bytes, 160 * 1024)) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile (r + f <= 48)");
     size_t n = (size_t) W * H * 3;
     DevBufs bufs; float *d_lin = nullptr, *d_srgb = nullptr, *d_out = nullptr;
     HIPCHK(bufs.get(d_lin, n * 4)); HIPCHK(bufs.get(d_srgb, n * 4)); HIPCHK(bufs.get(d_out, n * 4));
     hipLaunchKernelGGL(k_bitmap, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d_lin);
     hipLaunchKernelGGL(k_srgb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float *) d_lin, n, d_srgb);
-    const char *fenv = getenv("NORI_HIP_FILTER");
-    const bool direct = fenv && std::string(fenv) == "direct";
+    const bool direct = direct_early;
     const size_t lds_sep = ((size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 + (size_t) (NLM_BW + 2 * f) * (NLM_BH + 2 * f) + (size_t) (NLM_BH + 2 * f) * NLM_BW + (size_t) (2 * f + 1)) * sizeof(float);
-    if (!direct && lds_sep > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile");
-    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans_sep, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_sep));
+    if (!direct && lds_sep > std::min<size_t>(ctx->lds_bytes, 160 * 1024)) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile");
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     if (direct)
         hipLaunchKernelGGL(k_nlmeans, dim3((W + NLM_BW - 1) / NLM_BW, (H + NLM_BH - 1) / NLM_BH), dim3(NLM_BW, NLM_BH), lds, ctx->stream,
@@ -2222,9 +2230,8 @@ int nori_hip_filter_noalloc(NoriHipContext *ctx, int r, int f, float sigma, floa
         return fail(NORI_HIP_EINVAL, "nori_hip_filter_noalloc: image of " + std::to_string((size_t) W * H) + " pixels exceeds NORI_HIP_NOALLOC_MAX_PIXELS (" +
                     std::to_string((size_t) NORI_HIP_NOALLOC_MAX_PIXELS) + "); use nori_hip_filter");
     const size_t lds_sep = ((size_t) (NLM_BW + 2 * R) * (NLM_BH + 2 * R) * 3 + (size_t) (NLM_BW + 2 * f) * (NLM_BH + 2 * f) + (size_t) (NLM_BH + 2 * f) * NLM_BW + (size_t) (2 * f + 1)) * sizeof(float);
-    if (lds_sep > 160 * 1024) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile");
+    if (lds_sep > std::min<size_t>(ctx->lds_bytes, 160 * 1024)) return fail(NORI_HIP_EINVAL, "filter window + patch too large for the LDS tile");
     float *d_srgb = ctx->scratch_ptr;
-    HIPCHK(hipFuncSetAttribute((const void *) k_nlmeans_sep, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_sep));
     hipLaunchKernelGGL(k_bitmap_srgb, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, ctx->stream, (const float4 *) ctx->d_film, W, H, ctx->border, ctx->film_cols, d_srgb);
     hipLaunchKernelGGL(k_nlmeans_sep, dim3((W + NLM_BW - 1) / NLM_BW, (H + NLM_BH - 1) / NLM_BH), dim3(NLM_BW, NLM_BH), lds_sep, ctx->stream,
                        (const float *) d_srgb, d_rgb_srgb_out, W, H, r, f, sigma, h);
@@ -2240,7 +2247,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     HIPCHK(hipMemcpy(stripes.data(), ctx->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
     DevStats ds; std::memset(&ds, 0, sizeof(ds));
     for (const DevStats &t : stripes) {
-        ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims; ds.ext_visits += t.ext_visits; ds.culled += t.culled;
+        ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims; ds.ext_visits += t.ext_visits; ds.culled += t.culled; ds.dropped += t.dropped;
         ds.samples += t.samples; ds.closest += t.closest; ds.shadow += t.shadow; ds.invalid += t.invalid; ds.nodes += t.nodes; ds.prims += t.prims;
         for (int k = 0; k < 2; ++k) for (int j = 0; j < 10; ++j) ds.prof[k][j] += t.prof[k][j];
     }
@@ -2251,7 +2258,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     ctx->fold_ext_events();
     ctx->stats.extend_ms = ctx->ext_ms_acc; ctx->stats.extend_launches = ctx->ext_launches;
     ctx->stats.extend_rays = ds.ext_rays; ctx->stats.extend_boxes = ds.ext_nodes; ctx->stats.extend_prims = ds.ext_prims;
-    ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width; ctx->stats.shadow_rays_culled = ds.culled;
+    ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width; ctx->stats.shadow_rays_culled = ds.culled; ctx->stats.ss_paths_dropped = ds.dropped;
     if (ctx->profile) {
         static const char *names[10] = {"trips", "box_runs", "box_lanes", "prim_runs", "prim_lanes", "pop_runs", "pop_lanes", "refill_runs", "retired", "busy_lanes"};
         for (int k = 0; k < 2; ++k) {

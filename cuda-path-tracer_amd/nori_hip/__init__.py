@@ -37,7 +37,8 @@ class Stats(C.Structure):
     _fields_ = [("camera_samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("invalid_samples", C.c_uint64),
                 ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint64), ("render_ms", C.c_double),
                 ("extend_ms", C.c_double), ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("extend_boxes", C.c_uint64),
-                ("extend_prims", C.c_uint64), ("extend_visits", C.c_uint64), ("extend_width", C.c_uint64), ("shadow_rays_culled", C.c_uint64)]
+                ("extend_prims", C.c_uint64), ("extend_visits", C.c_uint64), ("extend_width", C.c_uint64), ("shadow_rays_culled", C.c_uint64),
+                ("ss_paths_dropped", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("lmin", "<f4", 3), ("lmax", "<f4", 3), ("rmin", "<f4", 3), ("rmax", "<f4", 3), ("left", "<u4"), ("right", "<u4"),
@@ -115,6 +116,7 @@ def hip_lib():
         L.nori_hip_group_render.argtypes = [vp, i32, i32, i32]
         L.nori_hip_group_reduce_films.argtypes = [vp]
         L.nori_hip_group_reduce_ms.argtypes = [vp, C.POINTER(C.c_double)]
+        L.nori_hip_group_plan.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, i32, C.POINTER(i32)]
         _hip = L
     return _hip
 
@@ -330,6 +332,16 @@ class Context:
 
 
 PARTITION_SPP, PARTITION_TILES = 0, 1
+
+
+def group_plan(n_members, member, spp_begin, spp_end, height, partition):
+    """nori_hip_group_plan: (spp_begin, spp_end, [(y0, y1), ...]) of one member of a group render; touches no device"""
+    L = hip_lib()
+    b, e, nb = C.c_int(), C.c_int(), C.c_int()
+    cap = (max(height, 1) + 31) // 32
+    bands = np.zeros((cap, 2), np.int32)
+    _hchk(L.nori_hip_group_plan(n_members, member, spp_begin, spp_end, height, partition, C.byref(b), C.byref(e), _vp(bands), cap, C.byref(nb)))
+    return b.value, e.value, [tuple(int(v) for v in bands[k]) for k in range(nb.value)]
 
 
 def device_count():

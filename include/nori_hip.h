@@ -185,6 +185,9 @@ typedef struct NoriHipStats {
     uint64_t extend_width;         /* boxes per node the trace stage of the last render walked: 2, 4, or 8 (quantised boxes) */
     uint64_t shadow_rays_culled;   /* emitter samples whose term was exactly zero and whose shadow ray was therefore not traced (NORI_HIP_CULL=0: none); the
                                       reference traces them (src/pathMisIntegrator.cpp:125): shadow_rays + shadow_rays_culled is its shadow-ray count */
+    uint64_t ss_paths_dropped;     /* subsurface bounces whose 4096 probe rays all left the shape: the reference would go on probing
+                                      (src/pathMisIntegrator.cpp:88-90), here the path ends and the radiance it had gathered so far IS splatted
+                                      with full weight (a bias, counted here so that it is never silent; 0 on every scene the reference ships) */
 } NoriHipStats;
 
 typedef struct NoriHipContext NoriHipContext;
@@ -327,6 +330,17 @@ int nori_hip_group_set_integrator(NoriHipGroup *g, int kind);
 int nori_hip_group_set_film_filter(NoriHipGroup *g, const float *table33, float radius);
 int nori_hip_group_clear_film(NoriHipGroup *g);
 int nori_hip_group_render(NoriHipGroup *g, int spp_begin, int spp_end, int partition);
+/* The work split of nori_hip_group_render as a pure function (no device is touched; usable for planning and tested on the CPU):
+ * what member `member` of `n_members` renders of samples [spp_begin, spp_end) of an image `height` rows high.
+ *   NORI_HIP_PARTITION_SPP    *out_spp_begin / *out_spp_end = its contiguous slice (the first (count mod n) members one sample longer;
+ *                             empty, begin == end, for members beyond the sample count), *out_n_bands = 0
+ *   NORI_HIP_PARTITION_TILES  the whole sample range, and its bands of 32 rows (band k belongs to member k mod n): *out_n_bands of
+ *                             them, the first min(*out_n_bands, max_bands) written to bands_y0y1 as (y0, y1) pairs (bands_y0y1 may be NULL)
+ * Over the members the slices tile the sample range, and the bands tile the rows, exactly once. */
+int nori_hip_group_plan(int n_members, int member, int spp_begin, int spp_end, int height, int partition,
+                        int *out_spp_begin, int *out_spp_end, int *bands_y0y1, int max_bands, int *out_n_bands);
+/* If a member fails inside nori_hip_group_render, the films of ALL members are cleared before the error is returned (a member may
+ * have rendered part of its share and the others have dropped what they held): the caller renders the job again from sample 0. */
 /* the all-reduce alone (for callers that render on the member contexts themselves), and its device time on the last call */
 int nori_hip_group_reduce_films(NoriHipGroup *g);
 int nori_hip_group_reduce_ms(NoriHipGroup *g, double *ms);

@@ -155,7 +155,7 @@ def test_c4_full_size_properties_on_the_device_built_tree():
     hs.close()
 
 
-@pytest.mark.skipif(os.environ.get("NORI_HIP_TEST_FULL") != "1", reason="two minutes of host work (450 MB of OBJ text, a one-thread SAH build): NORI_HIP_TEST_FULL=1 runs it")
+@pytest.mark.skipif(os.environ.get("NORI_HIP_TEST_FULL") == "0", reason="NORI_HIP_TEST_FULL=0: skip the minute of host work (450 MB of OBJ text, a one-thread SAH build)")
 def test_c4_full_size_hits_and_li_against_the_oracle(tmp_path):
     """The 10.0 M-triangle scene itself, not a reduced one: written as the reference's files, loaded by the oracle (its SAH tree, the
     reference's traversal order) and compared with the device-built tree on the GPU - closest hits the same primitive except on ties
@@ -185,7 +185,12 @@ def test_c4_full_size_hits_and_li_against_the_oracle(tmp_path):
     li = ctx.li_samples(st, np.zeros(n, np.uint64), rays=rays[:n])
     oli = o.li_rays(rays[:n], st, np.zeros(n, np.uint64))
     err = np.abs(li - oli).max(1) / np.maximum(np.abs(oli).max(1), 1e-3)
-    print("full-size C4: same primitive %.5f of camera rays, Li within 1e-3 for %.4f of %d samples, mean %.6f vs %.6f" % (same.mean(), (err < 1e-3).mean(), n, li.mean(), oli.mean()))
+    msg = "full-size C4: same primitive %.5f of bounce rays, Li within 1e-3 for %.4f (bit-identical %.4f) of %d samples, mean %.6f vs %.6f" % (
+        same.mean(), (err < 1e-3).mean(), (li == oli).all(1).mean(), n, li.mean(), oli.mean())
+    print(msg)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "c4_full_size_parity.txt"), "w").write(msg + "\n")
     assert (err < 1e-3).mean() > 0.95, (err < 1e-3).mean()
     assert abs(li.mean() - oli.mean()) < 0.03 * oli.mean()
     hs.close()

@@ -393,6 +393,17 @@ def test_subsurface_render_against_oracle(loaded):
     st = ctx.stats()
     assert abs(st["closest_rays"] - ost["closest"]) < 0.01 * ost["closest"]
     assert abs(st["shadow_rays"] + st["shadow_rays_culled"] - ost["shadow"]) < 0.01 * ost["shadow"]
+    # no bounce ran out of probe rays (a path that does keeps its partial radiance: a bias the library counts, never hides)
+    assert st["ss_paths_dropped"] == 0
+    os.environ["NORI_HIP_PIPELINE"] = "mega"
+    try:
+        hm = NH.HostScene(os.path.join(SCENES, SCENE_XML["cbox_subsurface"]), W, H, spp)
+        cm = hm.preprocess()
+    finally:
+        del os.environ["NORI_HIP_PIPELINE"]
+    cm.render(0, spp)
+    assert cm.stats()["ss_paths_dropped"] == 0
+    hm.close()
 
 
 def test_filter_pass_matches_oracle(loaded):

@@ -40,6 +40,40 @@ def test_tile_bands_partition_the_image():
         tile_bands(4, 4, 100)
 
 
+def test_group_plan_of_the_c_abi_tiles_samples_and_rows_for_1_to_8_members():
+    """nori_hip_group_plan (include/nori_hip.h): the split nori_hip_group_render makes, as a pure function - no GPU is touched.
+    For n = 1 .. 8 members: the spp slices tile the sample range in order, sizes within one of each other, empty for members
+    beyond the sample count; the bands of 32 rows tile the image rows exactly once, member i holding bands i, i + n, ..."""
+    import nori_hip as NH
+    for n in range(1, 9):
+        for b0, e0 in [(0, 16), (3, 4), (5, 5 + n), (0, 1), (7, 7 + 2 * n + 3), (100, 2148)]:
+            parts = [NH.group_plan(n, i, b0, e0, 600, NH.PARTITION_SPP) for i in range(n)]
+            assert all(p[2] == [] for p in parts)
+            assert parts[0][0] == b0 and parts[-1][1] == e0
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))              # contiguous, in member order, disjoint
+            sizes = [p[1] - p[0] for p in parts]
+            assert min(sizes) >= 0 and max(sizes) - min(sizes) <= 1 and sum(sizes) == e0 - b0
+            assert sizes == sorted(sizes, reverse=True)                              # the longer slices come first
+            if e0 - b0 < n:
+                assert sizes.count(0) == n - (e0 - b0)                              # spp < n: the last members idle
+        for height in (1, 31, 32, 33, 600, 1080, 2160, 32 * n, 32 * n + 1):
+            rows = np.zeros(height, np.int32)
+            for i in range(n):
+                sb, se, bands = NH.group_plan(n, i, 2, 9, height, NH.PARTITION_TILES)
+                assert (sb, se) == (2, 9)                                           # every member renders all samples of its rows
+                assert bands == [(y0, y1) for y0, y1 in tile_bands(i, n, height)]   # the same split bench.py's ranks use
+                for k, (y0, y1) in enumerate(bands):
+                    assert y0 == 32 * (i + k * n) and y1 == min(y0 + 32, height)
+                    rows[y0:y1] += 1
+            assert np.all(rows == 1)
+    # the slices agree with bench.py's strong-scaling split of a sample count
+    for total, n in [(64, 8), (10, 4), (3, 8)]:
+        assert [NH.group_plan(n, i, 0, total, 64, NH.PARTITION_SPP)[:2] for i in range(n)] == split_spp(total, n)
+    for bad in [(0, 0, 0, 4, 64, 0), (4, 4, 0, 4, 64, 0), (4, -1, 0, 4, 64, 0), (2, 0, 4, 4, 64, 0), (2, 0, 0, 4, 0, 1), (2, 0, 0, 4, 64, 7)]:
+        with pytest.raises(NH.NoriHipError):
+            NH.group_plan(*bad)
+
+
 def _rank(rank, world, port, out):
     import torch
     import torch.distributed as dist

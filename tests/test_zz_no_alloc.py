@@ -40,7 +40,16 @@ class DeviceBuffer:
         self.hip.hipFree(self.ptr)
 
 
-def test_filter_noalloc_matches_filter_on_two_calls_in_a_row():
+def device_free_bytes():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_filter_noalloc_matches_filter_on_two_calls_in_a_row(monkeypatch):
+    monkeypatch.delenv("NORI_HIP_FILTER", raising=False)               # (nori_hip_filter's other kernel is not what the entry point shares)
     xml = os.path.join(SCENES, "cbox", "cbox_path_mis.xml")
     for W, H, r, f in [(96, 80, 3, 10), (48, 40, 2, 4)]:
         hs = NH.HostScene(xml, W, H, 8)
@@ -48,8 +57,11 @@ def test_filter_noalloc_matches_filter_on_two_calls_in_a_row():
         ctx.render(0, 8)
         ref = ctx.filter(r, f, 0.5, 0.002)                              # the existing entry point (host output)
         buf = DeviceBuffer(W * H * 3 * 4)
+        ctx.synchronize()
+        free_before = device_free_bytes()
         ctx.filter_noalloc(buf.ptr, r, f, 0.5, 0.002)
         ctx.synchronize()
+        assert device_free_bytes() == free_before                       # the call took no device memory (and gave none back)
         out = buf.to_host((H, W, 3))
         buf.free()
         assert np.isfinite(out).all()
