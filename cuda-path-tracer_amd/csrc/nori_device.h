@@ -24,6 +24,100 @@ namespace nd {
 // (IEEE result), whereas __fsqrt_rn() lowers to the bare v_sqrt_f32 approximation: verified with scratch/fp_probe.hip.
 __device__ __forceinline__ float nd_sqrt(float x) { return sqrtf(x); }
 
+// ---- libm ---------------------------------------------------------------------------------------------------------------------
+// The reference calls cos / sin / acos / atan2 unqualified on floats, which with this toolchain are glibc's float routines (oracle/
+// orender.hpp, "unqualified <math.h> calls"), and their last bit decides comparisons further down a path (the z of a cosine-hemisphere
+// sample against 0, a sphere's uv against a checkerboard edge).  The device's own sinf / cosf differ from glibc's in the last place for
+// about one argument in five, so these restate glibc 2.35's algorithms instead:
+//   sincosf   sysdeps/ieee754/flt-32/s_sincosf.{c,h} (the ARM optimized-routines code): reduction by pi/2 and two degree-8 / degree-7
+//             polynomials, all in double, one rounding to float at the end
+//   acosf     sysdeps/ieee754/flt-32/e_acosf.c, atan2f: e_atan2f.c + s_atanf.c (fdlibm's float versions): float arithmetic as written
+// Checked bit for bit against the build container's libm on the host: every third float of [0, 2 pi] for sin and cos (362 M values),
+// every third float of [-1, 1] for acos (710 M), 300 M random pairs for atan2 - zero differences (scratch/glibc_libm_check.c).
+// glibc picks a variant of sincosf compiled with fused multiply-adds on CPUs that have them; the two variants differ before the final
+// rounding by parts in 1e16, i.e. in the float result about once in 2^29 calls, which is what "bit-identical" means below.
+struct NdSinCosTab { double c0, c1, c2, c3, c4; };
+__device__ __forceinline__ void nd_sincosf(float y, float *sinp, float *cosp) {
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    double x = (double) y; int n = 0;
+    if (top < 0x3f4u) {                                                   // |y| < pi/4 (compared on the top 12 bits, as glibc does)
+        if (top < 0x398u) { *sinp = y; *cosp = 1.0f; return; }            // |y| < 2^-12
+    } else if (top < 0x42fu) {                                            // |y| < 120: one multiply-subtract reduction
+        const double r = x * 0x1.45F306DC9C883p+23;                       // 2/pi * 2^24: the quadrant ends up in bits 24..31
+        n = ((int32_t) r + 0x800000) >> 24;
+        x = x - (double) n * 0x1.921FB54442D18p0;
+        if (((n & 3) == 1) || ((n & 3) == 2)) x = -x;                     // sign[n & 3]
+    } else { *sinp = sinf(y); *cosp = cosf(y); return; }                  // (never reached by the renderer: its arguments lie in [0, 2 pi])
+    const double sg = (n & 2) ? -1.0 : 1.0;                               // the second table negates the cosine polynomial
+    const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5, c3 = sg * -0x1.6c087e89a359dp-10, c4 = sg * 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double x2 = x * x, x4 = x2 * x2, x3 = x2 * x;
+    const double cc2 = c3 + x2 * c4, ss1 = s2 + x2 * s3, cc1 = c0 + x2 * c1;
+    const double x5 = x3 * x2, x6 = x4 * x2;
+    const double sv = x + x3 * s1, cv = cc1 + x4 * c2;
+    const float sf = (float) (sv + x5 * ss1), cf = (float) (cv + x6 * cc2);
+    if (n & 1) { *sinp = cf; *cosp = sf; } else { *sinp = sf; *cosp = cf; }
+}
+__device__ __forceinline__ float nd_acosf(float x) {
+    const float pi = __uint_as_float(0x40490fdau), pio2_hi = __uint_as_float(0x3fc90fdau), pio2_lo = __uint_as_float(0x33a22168u),
+        pS0 = __uint_as_float(0x3e2aaaabu), pS1 = __uint_as_float(0xbea6b090u), pS2 = __uint_as_float(0x3e4e0aa8u), pS3 = __uint_as_float(0xbd241146u),
+        pS4 = __uint_as_float(0x3a4f7f04u), pS5 = __uint_as_float(0x3811ef08u), qS1 = __uint_as_float(0xc019d139u), qS2 = __uint_as_float(0x4001572du),
+        qS3 = __uint_as_float(0xbf303361u), qS4 = __uint_as_float(0x3d9dc62eu);
+    const int32_t hx = (int32_t) __float_as_uint(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {                                                // |x| < 0.5
+        if (ix <= 0x23000000) return pio2_hi + pio2_lo;
+        const float z = x * x, p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5))))), q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) {                                                         // x < -0.5
+        const float z = (1.0f + x) * 0.5f, p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5))))), q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float sq = sqrtf(z), r = p / q, w = r * sq - pio2_lo;
+        return pi - 2.0f * (sq + w);
+    }
+    const float z = (1.0f - x) * 0.5f, sq = sqrtf(z), df = __uint_as_float(__float_as_uint(sq) & 0xfffff000u), c = (z - df * df) / (sq + df);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5))))), q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q, w = r * sq + c;
+    return 2.0f * (df + w);
+}
+__device__ __forceinline__ float nd_atanf(float x) {
+    const float hi[4] = {__uint_as_float(0x3eed6338u), __uint_as_float(0x3f490fdau), __uint_as_float(0x3f7b985eu), __uint_as_float(0x3fc90fdau)};
+    const float lo[4] = {__uint_as_float(0x31ac3769u), __uint_as_float(0x33222168u), __uint_as_float(0x33140fb4u), __uint_as_float(0x33a22168u)};
+    const float a0 = __uint_as_float(0x3eaaaaabu), a1 = __uint_as_float(0xbe4ccccdu), a2 = __uint_as_float(0x3e124925u), a3 = __uint_as_float(0xbde38e38u),
+        a4 = __uint_as_float(0x3dba2e6eu), a5 = __uint_as_float(0xbd9d8795u), a6 = __uint_as_float(0x3d886b35u), a7 = __uint_as_float(0xbd6ef16bu),
+        a8 = __uint_as_float(0x3d4bda59u), a9 = __uint_as_float(0xbd15a221u), a10 = __uint_as_float(0x3c8569d7u);
+    const int32_t hx = (int32_t) __float_as_uint(x), ix = hx & 0x7fffffff; int id;
+    if (ix >= 0x4c000000) { if (ix > 0x7f800000) return x + x; return hx > 0 ? hi[3] + lo[3] : -hi[3] - lo[3]; }
+    if (ix < 0x3ee00000) { if (ix < 0x31000000) return x; id = -1; }
+    else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) { if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); } else { id = 1; x = (x - 1.0f) / (x + 1.0f); } }
+        else { if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); } else { id = 3; x = -1.0f / x; } }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10))))), s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float hv = id == 0 ? hi[0] : id == 1 ? hi[1] : id == 2 ? hi[2] : hi[3], lv = id == 0 ? lo[0] : id == 1 ? lo[1] : id == 2 ? lo[2] : lo[3];
+    const float r = hv - ((x * (s1 + s2) - lv) - x);
+    return hx < 0 ? -r : r;
+}
+__device__ __forceinline__ float nd_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_2 = __uint_as_float(0x3fc90fdbu), pi = __uint_as_float(0x40490fdbu), pi_lo = __uint_as_float(0xb3bbbd2eu);
+    const int32_t hx = (int32_t) __float_as_uint(x), hy = (int32_t) __float_as_uint(y), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return nd_atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : m == 2 ? pi + tiny : -pi - tiny;
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000 || iy == 0x7f800000) return atan2f(y, x);        // (infinite coordinates: not a case a hit point produces)
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo; else if (hx < 0 && k < -60) z = 0.0f; else z = nd_atanf(fabsf(y / x));
+    return m == 0 ? z : m == 1 ? __uint_as_float(__float_as_uint(z) ^ 0x80000000u) : m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+}
+
 struct F3 { float x, y, z; };
 struct F2 { float x, y; };
 
@@ -636,8 +730,21 @@ struct DecS16x2 { __device__ __forceinline__ float4 operator()(uint32_t w) const
     return make_float4(x < -1.0f ? -1.0f : x, y < -1.0f ? -1.0f : y, 0.f, 0.f); } };
 // Color3f::toLinearRGB (src/common.cpp:208-222)
 __device__ __forceinline__ float srgb_to_linear(float v) { return v <= 0.04045f ? v * (1.0f / 12.92f) : powf((v + 0.055f) * (1.0f / 1.055f), 2.4f); }
-// ImageTexture<Color3f>::eval
+// Checkerboard<T>::eval (src/checkerboard.cpp:32-55): which of the two values uv falls on.  fmodf is exact, so this is the
+// reference's decision bit for bit.
+__device__ __forceinline__ bool checker_first(const NoriHipTexture &t, F2 uv) {
+    float x = (uv.x / t.scale[0]) - t.delta[0], y = (uv.y / t.scale[1]) - t.delta[1];
+    float modx = fmodf(x, 2.0f), mody = fmodf(y, 2.0f);
+    if (x < 0) modx = fmodf(fabsf(x) + 1, 2.0f);
+    if (y < 0) mody = fmodf(fabsf(y) + 1, 2.0f);
+    return (modx <= 1 && mody <= 1) || (modx >= 1 && mody >= 1);
+}
+// ImageTexture<Color3f>::eval / Checkerboard<Color3f>::eval
 __device__ __forceinline__ F3 tex_color(const DevScene &sc, const NoriHipTexture &t, F2 uv) {
+    if (t.kind == NORI_HIP_TEX_CHECKER_COLOR) {
+        const float *v = reinterpret_cast<const float *>(sc.tex_data + t.offset) + (checker_first(t, uv) ? 0 : 3);
+        return f3(v[0], v[1], v[2]);
+    }
     F2 c = tex_coords(t, uv);
     float4 rgb = tex_lookup(sc, t, c.y, c.x, DecRgba8());                  // tex2D(image_tex, y, x) / row = x*rows, col = y*cols
     if (t.lookup == NORI_HIP_LOOKUP_NEAREST) return f3(rgb.x, rgb.y, rgb.z);
@@ -645,6 +752,14 @@ __device__ __forceinline__ F3 tex_color(const DevScene &sc, const NoriHipTexture
 }
 // BumpMap::eval / NormalMap::eval: the new shading normal
 __device__ __forceinline__ F3 tex_normal(const DevScene &sc, const NoriHipTexture &t, F2 uv, const Frame &fr) {
+    // the CPU renderer's bump_map over a Texture<float> (src/bumpMap.cpp:44-50): the value is assigned to the normal as it is
+    if (t.kind == NORI_HIP_TEX_CHECKER_FLOAT) return f3(reinterpret_cast<const float *>(sc.tex_data + t.offset)[checker_first(t, uv) ? 0 : 1]);
+    if (t.kind == NORI_HIP_TEX_IMAGE_FLOAT) {                              // ImageTexture<float>::eval, src/imagetexture.cpp:26-46
+        F2 q = tex_coords(t, uv);
+        const int row = (int) (q.x * (float) t.height), col = (int) (q.y * (float) t.width);
+        const uint32_t w = reinterpret_cast<const uint32_t *>(sc.tex_data + t.offset)[(size_t) row * t.width + col];
+        return f3((float) (w & 0xffu) / 255.0f);
+    }
     F2 c = tex_coords(t, uv);
     if (t.kind == NORI_HIP_TEX_BUMP) {
         float4 g = tex_lookup(sc, t, c.x, c.y, DecS16x2());                // tex2D(image_tex_x / _y, x, y)
@@ -673,8 +788,8 @@ __device__ __forceinline__ void surface_from_hit(const DevScene &sc, const Ray &
         F3 pl = s.p - c;
         float frac = pl.z / shp.radius;
         if (frac < -1) frac = -1; else if (frac > 1) frac = 1;
-        float theta = acosf(frac) / ND_PI;
-        float phi = (atan2f(pl.y, pl.x) + ND_PI) / (2 * ND_PI);
+        float theta = nd_acosf(frac) / ND_PI;
+        float phi = (nd_atan2f(pl.y, pl.x) + ND_PI) / (2 * ND_PI);
         s.uv = f2(phi, theta);
     } else {
         const NoriHipShadePrim &sp = sc.shade[hit.pos];
@@ -692,7 +807,12 @@ __device__ __forceinline__ void surface_from_hit(const DevScene &sc, const Ray &
             s.sh.set(g); s.geo_n = g;
         }
     }
-    if (EXT && shp.normal_tex) { F3 n = tex_normal(sc, sc.textures[shp.normal_tex - 1], s.uv, s.sh); s.sh.set(n); }
+    if (EXT && shp.normal_tex) {
+        const NoriHipTexture &nt = sc.textures[shp.normal_tex - 1];
+        // the float kinds are the CPU renderer's modifier: meshes with vertex normals only (src/mesh.cpp:151-164)
+        const bool cpu_kind = nt.kind == NORI_HIP_TEX_CHECKER_FLOAT || nt.kind == NORI_HIP_TEX_IMAGE_FLOAT;
+        if (!cpu_kind || (!(flags & 0x40000000u) && (shp.flags & 1u))) { F3 n = tex_normal(sc, nt, s.uv, s.sh); s.sh.set(n); }
+    }
 }
 
 // PerspectiveCamera::sampleRay (src/perspective.cpp:90-111); Transform::operator* (include/nori/transform.h:68-81)
@@ -720,15 +840,15 @@ __device__ __forceinline__ void camera_ray(const DevScene &sc, F2 ps, Ray &ray) 
 __device__ __forceinline__ F3 square_to_cosine_hemisphere(F2 s) {
     float r = nd_sqrt(s.x);
     float theta = 2 * ND_PI * s.y;
-    float sn, cs; sincosf(theta, &sn, &cs);
+    float sn, cs; nd_sincosf(theta, &sn, &cs);
     float dx = r * cs, dy = r * sn;
     return f3(dx, dy, nd_sqrt(1.0f - dx * dx - dy * dy));
 }
 __device__ __forceinline__ F3 square_to_beckmann(F2 s, float alpha) {
     float inner = 1.0f / (1.0f - alpha * alpha * logf(1.0f - s.x));
-    float theta = acosf(nd_sqrt(inner));
+    float theta = nd_acosf(nd_sqrt(inner));
     float phi = s.y * 2.0f * ND_PI;
-    float st, ct, sp, cp; sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+    float st, ct, sp, cp; nd_sincosf(theta, &st, &ct); nd_sincosf(phi, &sp, &cp);
     return f3(st * cp, st * sp, ct);
 }
 __device__ __forceinline__ F3 square_to_uniform_triangle(F2 s) {
@@ -875,7 +995,7 @@ __device__ __forceinline__ F3 emitter_sample(const DevScene &sc, const NoriHipEm
     const NoriHipShape &shp = sc.shapes[em.shape];
     F3 p, n; float apdf;
     if (shp.type == NORI_HIP_SHAPE_SPHERE) {                              // src/sphere.cpp:143-149, src/warp.cpp:26-31,198-203
-        float phi = 2 * ND_PI * sample.x, sn, cs; sincosf(phi, &sn, &cs);
+        float phi = 2 * ND_PI * sample.x, sn, cs; nd_sincosf(phi, &sn, &cs);
         float z = 2.0f * sample.y - 1.0f; float r = nd_sqrt(1.0f - (z * z));
         F3 q = f3(cs * r, sn * r, z);
         p = f3(shp.center) + shp.radius * q; n = q;
@@ -910,7 +1030,7 @@ __device__ __forceinline__ F2 env_uv(const DevScene &sc, F3 dir) {        // Sph
     const float *f = sc.env.frame;
     F3 p = f3(dot(dir, f3(f[0], f[1], f[2])), dot(dir, f3(f[3], f[4], f[5])), dot(dir, f3(f[6], f[7], f[8])));
     float z = p.z < -1.f ? -1.f : p.z > 1.f ? 1.f : p.z;
-    return f2(acosf(z) / ND_PI, (atan2f(p.y, p.x) + ND_PI) / (2 * ND_PI));
+    return f2(nd_acosf(z) / ND_PI, (nd_atan2f(p.y, p.x) + ND_PI) / (2 * ND_PI));
 }
 __device__ __forceinline__ F3 env_eval(const DevScene &sc, F3 dir) {
     F3 c = tex_color(sc, sc.textures[sc.env.texture - 1], env_uv(sc, dir));
@@ -938,7 +1058,7 @@ __device__ __forceinline__ F3 env_sample(const DevScene &sc, F2 sample, float &p
     const uint32_t i = (uint32_t) idx / sc.env_w, j = (uint32_t) idx % sc.env_w;
     const float u = ((float) i + sx) / (float) sc.env_h, v = ((float) j + sample.y) / (float) sc.env_w;
     const float theta = u * ND_PI, phi = v * 2 * ND_PI - ND_PI;
-    float st, ct, sp, cp; sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+    float st, ct, sp, cp; nd_sincosf(theta, &st, &ct); nd_sincosf(phi, &sp, &cp);
     const float *f = sc.env.frame;
     F3 l = f3(st * cp, st * sp, ct);
     F3 d = (f3(f[0], f[1], f[2]) * l.x + f3(f[3], f[4], f[5]) * l.y) + f3(f[6], f[7], f[8]) * l.z;
@@ -986,7 +1106,7 @@ __device__ __forceinline__ F2 ss_sample_disk(F2 s2, float cs, float cd) {
         r0 = r0 - f / df;
     }
     float theta = 2.0f * ND_PI * s2.y;
-    float sn, c; sincosf(theta, &sn, &c);
+    float sn, c; nd_sincosf(theta, &sn, &c);
     return f2(r0 * c, r0 * sn);
 }
 // a closest-hit query that only sees the records of shape `mask` (BVH::rayIntersect's `mask` argument, src/bvh.cpp:404,438),

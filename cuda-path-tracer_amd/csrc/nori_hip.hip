@@ -139,6 +139,17 @@ __global__ __launch_bounds__(256) void k_env_weights(DevScene sc, uint32_t w, ui
     const F3 c = tex_color(sc, sc.textures[sc.env.texture - 1], f2(u, v));
     weights[k] = (c.x + c.y + c.z + 1e-4f) * sinf(u * ND_PI);
 }
+// one texture of the uploaded scene at n uv pairs (nori_hip_texture_eval)
+__global__ __launch_bounds__(256) void k_texture_eval(DevScene sc, uint32_t k, size_t n, const float *uv, const float *nrm, float *out) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const NoriHipTexture &t = sc.textures[k];
+    const F2 q = f2(uv[2 * i], uv[2 * i + 1]);
+    F3 r;
+    if (t.kind == NORI_HIP_TEX_COLOR || t.kind == NORI_HIP_TEX_CHECKER_COLOR) r = tex_color(sc, t, q);
+    else { Frame fr; fr.set(f3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2])); r = tex_normal(sc, t, q, fr); }
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
 // n draws of pcg32.seed(state, seq) by one lane (known-answer test of the device sampler, ext/pcg32/pcg32-demo.out)
 __global__ void k_pcg32(uint64_t state, uint64_t seq, unsigned int n, uint32_t *out_u32, float *out_f32) {
     Pcg32 r; r.seed(state, seq);
@@ -1316,7 +1327,7 @@ struct NoriHipContext {
     size_t trace_lds_wide = 0;
     NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
     NoriHipShape *d_shapes = nullptr; NoriHipEmitter *d_emitters = nullptr; float *d_cdf = nullptr;
-    NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr;
+    NoriHipTexture *d_textures = nullptr; uint8_t *d_tex_data = nullptr; uint32_t n_textures = 0;
     float *d_env_cdf = nullptr;       // environment emitter: CDF over its (u, v) cells
     float *d_filt = nullptr; float filt_radius = 0.f;   // nori_hip_set_film_filter (kept across scene uploads)
     bool ext = false;                 // the scene has images or subsurface shapes: the EXT kernel variants run
@@ -1392,7 +1403,7 @@ struct NoriHipContext {
         hipFree(d_nodes8); d_nodes8 = nullptr; n_nodes8 = 0;
         hipFree(d_env_cdf); d_env_cdf = nullptr;
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
-        hipFree(d_textures); hipFree(d_tex_data); d_textures = nullptr; d_tex_data = nullptr; ext = false;
+        hipFree(d_textures); hipFree(d_tex_data); d_textures = nullptr; d_tex_data = nullptr; n_textures = 0; ext = false;
         d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr; d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr;
         have_scene = false;
     }
@@ -1614,13 +1625,15 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         if (s.bsdf < 0 || s.bsdf > NORI_HIP_BSDF_SUBSURFACE) return fail(NORI_HIP_EINVAL, "unknown BSDF kind");
         if (s.bsdf == NORI_HIP_BSDF_SUBSURFACE) { ext = true; if (!(s.ss_cs > 0.f) || !(s.ss_cd > 0.f)) return fail(NORI_HIP_EINVAL, "subsurface shape without ss_cs / ss_cd"); }
         if (s.albedo_tex > d->n_textures || s.normal_tex > d->n_textures) return fail(NORI_HIP_EINVAL, "shape names a texture out of range");
-        if (s.albedo_tex && d->textures[s.albedo_tex - 1].kind != NORI_HIP_TEX_COLOR) return fail(NORI_HIP_EINVAL, "albedo texture is not a colour image");
-        if (s.normal_tex && d->textures[s.normal_tex - 1].kind == NORI_HIP_TEX_COLOR) return fail(NORI_HIP_EINVAL, "normal modifier is a colour image");
+        if (s.albedo_tex && d->textures[s.albedo_tex - 1].kind != NORI_HIP_TEX_COLOR && d->textures[s.albedo_tex - 1].kind != NORI_HIP_TEX_CHECKER_COLOR) return fail(NORI_HIP_EINVAL, "albedo texture is not a colour texture");
+        if (s.normal_tex && (d->textures[s.normal_tex - 1].kind == NORI_HIP_TEX_COLOR || d->textures[s.normal_tex - 1].kind == NORI_HIP_TEX_CHECKER_COLOR)) return fail(NORI_HIP_EINVAL, "normal modifier is a colour texture");
         if (s.albedo_tex || s.normal_tex) ext = true;
     }
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const NoriHipTexture &t = d->textures[i];
-        if (t.kind > NORI_HIP_TEX_NORMAL || t.lookup > NORI_HIP_LOOKUP_BILINEAR) return fail(NORI_HIP_EINVAL, "unknown texture kind or lookup");
+        if (t.kind > NORI_HIP_TEX_IMAGE_FLOAT || t.lookup > NORI_HIP_LOOKUP_BILINEAR) return fail(NORI_HIP_EINVAL, "unknown texture kind or lookup");
+        if (t.kind == NORI_HIP_TEX_CHECKER_COLOR && (t.width != 6 || t.height != 1)) return fail(NORI_HIP_EINVAL, "checkerboard colour texture must carry six floats (width 6, height 1)");
+        if (t.kind == NORI_HIP_TEX_CHECKER_FLOAT && (t.width != 2 || t.height != 1)) return fail(NORI_HIP_EINVAL, "checkerboard float texture must carry two floats (width 2, height 1)");
         if (t.width == 0 || t.height == 0 || (t.offset & 3u) || t.offset + (uint64_t) t.width * t.height * 4u > d->n_tex_bytes)
             return fail(NORI_HIP_EINVAL, "texture " + std::to_string(i) + " lies outside tex_data");
         if (t.scale[0] == 0.f || t.scale[1] == 0.f) return fail(NORI_HIP_EINVAL, "texture scale is zero");
@@ -1719,7 +1732,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     if ((rc = upload(ctx->d_cdf, d->cdf, d->n_cdf))) return rc;
     if ((rc = upload(ctx->d_textures, d->textures, d->n_textures))) return rc;
     if ((rc = upload(ctx->d_tex_data, d->tex_data, d->n_textures ? (size_t) d->n_tex_bytes : 0))) return rc;
-    ctx->ext = ext; ctx->has_ss = false;
+    ctx->ext = ext; ctx->has_ss = false; ctx->n_textures = d->n_textures;
     for (uint32_t i = 0; i < d->n_shapes; ++i) if (d->shapes[i].bsdf == NORI_HIP_BSDF_SUBSURFACE) ctx->has_ss = true;
     ctx->n_prims = n_records; ctx->n_nodes = device_build ? ctx->lbvh.n_nodes : d->n_nodes;
     DevScene &sc = ctx->sc;
@@ -1894,6 +1907,28 @@ int nori_hip_bsdf_vectors(NoriHipContext *ctx, const NoriHipShape *bsdf, size_t 
     hipLaunchKernelGGL(k_bsdf_vectors, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, *bsdf, n, (const float *) d_wi, (const float *) d_s, (const float *) d_s2, (const float *) d_wo, d_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out, n * 48, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NORI_HIP_OK;
+}
+
+int nori_hip_texture_eval(NoriHipContext *ctx, uint32_t texture, size_t n, const float *uv, const float *nrm, float *out) {
+    SCENECHK(ctx);
+    if (n == 0) return NORI_HIP_OK;
+    if (!uv || !out) return fail(NORI_HIP_EINVAL, "null buffer");
+    if (!ctx->d_textures || !ctx->sc.textures) return fail(NORI_HIP_ESTATE, "the uploaded scene has no textures");
+    NoriHipTexture t;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (texture >= ctx->n_textures) return fail(NORI_HIP_EINVAL, "texture index out of range");
+    HIPCHK(hipMemcpy(&t, ctx->d_textures + texture, sizeof(t), hipMemcpyDeviceToHost));
+    const bool colour = t.kind == NORI_HIP_TEX_COLOR || t.kind == NORI_HIP_TEX_CHECKER_COLOR;
+    if (!colour && !nrm) return fail(NORI_HIP_EINVAL, "a normal modifier needs the shading normals it modifies");
+    DevBufs bufs; float *d_uv = nullptr, *d_n = nullptr, *d_out = nullptr;
+    HIPCHK(bufs.get(d_uv, n * 8)); HIPCHK(hipMemcpyAsync(d_uv, uv, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!colour) { HIPCHK(bufs.get(d_n, n * 12)); HIPCHK(hipMemcpyAsync(d_n, nrm, n * 12, hipMemcpyHostToDevice, ctx->stream)); }
+    HIPCHK(bufs.get(d_out, n * 12));
+    hipLaunchKernelGGL(k_texture_eval, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sc, texture, n, (const float *) d_uv, (const float *) d_n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, n * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return NORI_HIP_OK;
 }

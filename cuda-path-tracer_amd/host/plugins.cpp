@@ -249,6 +249,71 @@ private:
 };
 NORI_REGISTER_CLASS(ConstantColorTexture, "constant_color")
 
+/// The procedural and scalar textures of the CPU renderer.  They cross the C ABI as NoriHipTexture entries without an image: the few
+/// constants they need travel in tex_data, and the device evaluates them per lookup (include/nori_hip.h, NORI_HIP_TEX_CHECKER_* / _IMAGE_FLOAT).
+static void constantsAsTexels(ImageData &img, const float *v, uint32_t n) {
+    img.meta.width = n; img.meta.height = 1; img.texels.resize((size_t) n * 4); std::memcpy(img.texels.data(), v, (size_t) n * 4);
+}
+static void proceduralCommon(const PropertyList &p, ImageData &img, uint32_t kind) {
+    std::memset(&img.meta, 0, sizeof(img.meta));
+    Point2f delta = p.getPoint2("delta", Point2f(0.f, 0.f)), scale = p.getVector2("scale", Point2f(1.f, 1.f));
+    img.meta.kind = kind; img.meta.lookup = NORI_HIP_LOOKUP_NEAREST;
+    img.meta.delta[0] = delta.x; img.meta.delta[1] = delta.y; img.meta.scale[0] = scale.x; img.meta.scale[1] = scale.y;
+}
+/// checkerboard_color (src/checkerboard.cpp:73-79, eval :32-55)
+class CheckerboardColor : public ColorTexture {
+public:
+    explicit CheckerboardColor(const PropertyList &p) {
+        proceduralCommon(p, m_img, NORI_HIP_TEX_CHECKER_COLOR);
+        const Color3f a = p.getColor("value1", Color3f(0.f)), b = p.getColor("value2", Color3f(1.f));
+        const float v[6] = {a.x, a.y, a.z, b.x, b.y, b.z};
+        constantsAsTexels(m_img, v, 6);
+    }
+    const ImageData *image() const override { return &m_img; }
+    std::string toString() const override { return "Checkerboard[]"; }
+private:
+    ImageData m_img;
+};
+NORI_REGISTER_CLASS(CheckerboardColor, "checkerboard_color")
+/// checkerboard_float (src/checkerboard.cpp:65-71) and constant_float (src/consttexture.cpp:38-41: one value everywhere)
+class CheckerboardFloat : public ColorTexture {
+public:
+    explicit CheckerboardFloat(const PropertyList &p, bool constant = false) {
+        proceduralCommon(p, m_img, NORI_HIP_TEX_CHECKER_FLOAT);
+        float v[2] = {p.getFloat("value1", 0.f), p.getFloat("value2", 1.f)};
+        if (constant) v[0] = v[1] = p.getFloat("value", 0.f);
+        constantsAsTexels(m_img, v, 2);
+        m_constant = constant;
+    }
+    bool scalar() const override { return true; }
+    const ImageData *image() const override { return &m_img; }
+    std::string toString() const override { return m_constant ? "ConstantTexture[]" : "Checkerboard[]"; }
+private:
+    ImageData m_img; bool m_constant;
+};
+class ConstantFloatTexture : public CheckerboardFloat { public: explicit ConstantFloatTexture(const PropertyList &p) : CheckerboardFloat(p, true) {} };
+NORI_REGISTER_CLASS(CheckerboardFloat, "checkerboard_float")
+NORI_REGISTER_CLASS(ConstantFloatTexture, "constant_float")
+/// image_float (src/imagetexture.cpp:26-46, 81-95): a grey image (cv::imread(..., GRAYSCALE)), truncating lookup, value / 255
+class ImageFloatTexture : public ColorTexture {
+public:
+    explicit ImageFloatTexture(const PropertyList &p) {
+        proceduralCommon(p, m_img, NORI_HIP_TEX_IMAGE_FLOAT);
+        int cols, rows, ch; std::vector<uint8_t> px; loadImageFile(p.getString("filename"), cols, rows, ch, px);
+        m_img.meta.width = (uint32_t) cols; m_img.meta.height = (uint32_t) rows; m_img.texels.resize((size_t) cols * rows * 4);
+        for (size_t i = 0; i < (size_t) cols * rows; ++i) {
+            const uint8_t g = ch == 1 ? px[i] : (uint8_t) ((px[3 * i] * 4899 + px[3 * i + 1] * 9617 + px[3 * i + 2] * 1868 + 8192) >> 14);   // (fixed-point BT.601 luma, as for bump maps)
+            m_img.texels[4 * i] = m_img.texels[4 * i + 1] = m_img.texels[4 * i + 2] = g; m_img.texels[4 * i + 3] = 255;
+        }
+    }
+    bool scalar() const override { return true; }
+    const ImageData *image() const override { return &m_img; }
+    std::string toString() const override { return "ImageTexture[]"; }
+private:
+    ImageData m_img;
+};
+NORI_REGISTER_CLASS(ImageFloatTexture, "image_float")
+
 /// image_color texture (cuda/nori/imagetexture.cpp.cu:29-52; src/imagetexture.cpp:100-111)
 class ImageColorTexture : public ColorTexture {
 public:
@@ -293,10 +358,24 @@ private:
 };
 NORI_REGISTER_CLASS(SphereMap, "sphereMap")
 
-/// bump_map (cuda/nori/bumpMap.cpp.cu:31-115): grey image -> Sobel gradients in x and y, 16-bit signed
+/// bump_map.  With a `filename` property it is the CUDA fork's (cuda/nori/bumpMap.cpp.cu:31-115): grey image -> Sobel gradients in x
+/// and y, 16-bit signed.  Without one it is the CPU renderer's (src/bumpMap.cpp:9-61): a Texture<float> child named "bump_map"
+/// whose value is assigned to the shading normal as it is (n = (v, v, v): that is what the reference's adjustNormal does).
 class BumpMap : public NormalModifier {
 public:
+    ~BumpMap() override { delete m_child; }
+    void addChild(NoriObject *obj) override {
+        if (obj->getClassType() != ETexture) throw NoriException::format("BumpMap::addChild(<%s>) is not supported!", classTypeName(obj->getClassType()).c_str());
+        if (obj->getIdName() != "bump_map") throw NoriException("The name of this texture does not match any field!");
+        if (m_child || m_fromFile) throw NoriException("There is already an bump_map defined!");
+        ColorTexture *t = static_cast<ColorTexture *>(obj);
+        if (!t->scalar()) throw NoriException("BumpMap: the bump_map texture must be a float texture (constant_float, checkerboard_float, image_float)");
+        m_child = t;
+    }
+    void activate() override { if (!m_child && !m_fromFile) throw NoriException("There is no texture with name bump_map given!"); }
     explicit BumpMap(const PropertyList &p) {
+        if (!p.has("filename")) { std::memset(&m_img.meta, 0, sizeof(m_img.meta)); return; }      // the CPU renderer's form: the texture comes as a child
+        m_fromFile = true;
         imageCommon(p, m_img, NORI_HIP_TEX_BUMP);
         const float height = p.getFloat("height", 5), gradDelta = p.getFloat("grad_delta", 0);
         int cols, rows, ch; std::vector<uint8_t> px; loadImageFile(p.getString("filename"), cols, rows, ch, px);
@@ -319,10 +398,10 @@ public:
             std::memcpy(&m_img.texels[((size_t) r * cols + c) * 4], &sx, 2); std::memcpy(&m_img.texels[((size_t) r * cols + c) * 4 + 2], &sy, 2);
         }
     }
-    const ImageData *image() const override { return &m_img; }
+    const ImageData *image() const override { return m_child ? m_child->image() : &m_img; }
     std::string toString() const override { return "BumpMap[]"; }
 private:
-    ImageData m_img;
+    ImageData m_img; bool m_fromFile = false; ColorTexture *m_child = nullptr;
 };
 NORI_REGISTER_CLASS(BumpMap, "bump_map")
 
@@ -350,6 +429,7 @@ public:
         if (obj->getClassType() != NoriObject::ETexture) throw NoriException::format("%s::addChild(<%s>) is not supported!", cls, NoriObject::classTypeName(obj->getClassType()).c_str());
         if (obj->getIdName() != "albedo") throw NoriException("The name of this texture does not match any field!");
         if (m_has) throw NoriException("There is already an albedo defined!");
+        if (static_cast<ColorTexture *>(obj)->scalar()) throw NoriException::format("%s: the albedo texture must be a colour texture", cls);
         m_tex = static_cast<ColorTexture *>(obj); m_has = true;
         if (!m_tex->image()) m_value = m_tex->constantValue();
     }

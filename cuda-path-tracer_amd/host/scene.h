@@ -24,6 +24,9 @@ public:
     EClassType getClassType() const override { return ETexture; }
     virtual Color3f constantValue() const { return Color3f(0.f); }
     virtual const ImageData *image() const { return nullptr; }
+    /// true for the Texture<float> plugins (constant_float, checkerboard_float, image_float): they share the <texture> tag and class
+    /// type with the colour textures, and a slot that wants the other kind says so instead of reinterpreting the object
+    virtual bool scalar() const { return false; }
 };
 /// NormalModifier (include/nori/normalModifier.h; cuda/include/nori/bumpMap.h, normalMap.h)
 class NormalModifier : public NoriObject {

@@ -103,6 +103,7 @@ def hip_lib():
         L.nori_hip_synchronize.argtypes = [vp]
         L.nori_hip_bsdf_vectors.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp]
         L.nori_hip_pcg32.argtypes = [vp, C.c_uint64, C.c_uint64, sz, vp, vp]
+        L.nori_hip_texture_eval.argtypes = [vp, C.c_uint32, sz, vp, vp, vp]
         L.nori_hip_device_count.argtypes = [C.POINTER(i32)]
         L.nori_hip_group_create.argtypes = [vp, i32, C.POINTER(vp)]
         L.nori_hip_group_destroy.argtypes = [vp]
@@ -248,6 +249,14 @@ class Context:
         wo = None if wo is None else np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
         out = np.zeros((len(wi), 12), np.float32)
         _hchk(self.L.nori_hip_bsdf_vectors(self.h, _vp(b), len(wi), _vp(wi), _vp(sample), _vp(sample2), _vp(wo), _vp(out)))
+        return out
+
+    def texture_eval(self, k, uv, nrm=None):
+        """nori_hip_texture_eval: textures[k] (0-based) of the uploaded scene at uv; nrm for normal modifiers"""
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        nrm = None if nrm is None else np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+        out = np.zeros((len(uv), 3), np.float32)
+        _hchk(self.L.nori_hip_texture_eval(self.h, k, len(uv), _vp(uv), _vp(nrm), _vp(out)))
         return out
 
     def pcg32(self, state, seq, n, floats=False):

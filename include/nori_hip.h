@@ -38,7 +38,11 @@ enum { NORI_HIP_SHAPE_MESH = 0, NORI_HIP_SHAPE_SPHERE = 1 };
  * reference's own test files, BSDF sampling only; src/directMisIntegrator.cpp — one bounce, emitter + BSDF sampling) */
 enum { NORI_HIP_INTEGRATOR_PATH_MIS = 0, NORI_HIP_INTEGRATOR_PATH_MATS = 1, NORI_HIP_INTEGRATOR_DIRECT_MIS = 2 };
 /* image kinds and lookup modes (cuda/nori/imagetexture.cpp.cu, bumpMap.cpp.cu, normalMap.cpp.cu; src/imagetexture.cpp) */
-enum { NORI_HIP_TEX_COLOR = 0, NORI_HIP_TEX_BUMP = 1, NORI_HIP_TEX_NORMAL = 2 };
+enum { NORI_HIP_TEX_COLOR = 0, NORI_HIP_TEX_BUMP = 1, NORI_HIP_TEX_NORMAL = 2,
+       /* procedural and scalar textures of the CPU renderer (evaluated on the device from a few constants, no image): */
+       NORI_HIP_TEX_CHECKER_COLOR = 3,   /* Checkerboard<Color3f>, "checkerboard_color" (src/checkerboard.cpp:32-55): an albedo */
+       NORI_HIP_TEX_CHECKER_FLOAT = 4,   /* Checkerboard<float>, "checkerboard_float"; ConstantTexture<float>, "constant_float" (value1 = value2) */
+       NORI_HIP_TEX_IMAGE_FLOAT = 5 };   /* ImageTexture<float>, "image_float" (src/imagetexture.cpp:26-46): grey image, truncating lookup, v / 255 */
 enum { NORI_HIP_LOOKUP_NEAREST = 0, NORI_HIP_LOOKUP_BILINEAR = 1 };
 
 /*
@@ -102,6 +106,13 @@ typedef struct NoriHipShape {
  *   NORI_HIP_TEX_COLOR / _NORMAL : texel = R, G, B, A bytes (the fork converts BGR -> RGBA before upload)
  *   NORI_HIP_TEX_BUMP            : texel = two int16: Sobel d/dx, d/dy of the grey image (cv::Sobel, CV_16S, ksize 3,
  *                                  scale = height, delta = grad_delta), read as value / 32767
+ *   NORI_HIP_TEX_CHECKER_COLOR   : no image: width = 6, height = 1, the "texels" are six floats, value1 rgb then value2 rgb; the
+ *                                  colour at uv is Checkerboard::eval's (src/checkerboard.cpp:32-55: fmod of uv / scale - delta by 2)
+ *   NORI_HIP_TEX_CHECKER_FLOAT   : the same with width = 2: value1, value2 (a constant_float has value1 = value2)
+ *   NORI_HIP_TEX_IMAGE_FLOAT     : texel = R, G, B, A bytes with R = the grey value; row = x * rows, col = y * cols, value / 255
+ * The two float kinds can only be a shape's normal_tex: the CPU renderer's bump_map (src/bumpMap.cpp:44-50) takes a
+ * Texture<float> child and, as written, ASSIGNS its value v to the shading normal - n = (v, v, v), not normalised - on meshes
+ * that have vertex normals (src/mesh.cpp:151-164; Sphere::setHitInformation does not look at the modifier).  Restated as written.
  * lookup: NORI_HIP_LOOKUP_BILINEAR is the CUDA fork's tex2D (wrap addressing, normalised coordinates, 8-bit blend
  * weights) and, for colour images, its sRGB -> linear conversion; NORI_HIP_LOOKUP_NEAREST is the CPU renderer's
  * lookup for colour images (src/imagetexture.cpp:49-77: row = x*rows, col = y*cols, no colour-space conversion).
@@ -257,6 +268,12 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
  * and "chi2test" run on it.  No scene needs to be uploaded. */
 int nori_hip_bsdf_vectors(NoriHipContext *ctx, const NoriHipShape *bsdf, size_t n, const float *wi, const float *sample, const float *sample2,
                           const float *wo, float *out);
+/* The device's texture code alone: textures[texture] of the uploaded scene (0-based) at n uv pairs.  Colour kinds (NORI_HIP_TEX_COLOR,
+ * _CHECKER_COLOR): out = the colour, Texture<Color3f>::eval(uv) (cuda/nori/imagetexture.cpp.cu:12-26, src/checkerboard.cpp:32-55).
+ * Normal-modifier kinds: out = the new shading normal for the shading normal nrm[i] (3 floats each, required), NormalModifier::eval /
+ * adjustNormal (cuda/nori/bumpMap.cpp.cu:10-27, normalMap.cpp.cu:10-24, src/bumpMap.cpp:44-50).  3 floats per query.  Test entry:
+ * the reference has no counterpart call, its textures are only reached through BSDF::eval and setHitInformation. */
+int nori_hip_texture_eval(NoriHipContext *ctx, uint32_t texture, size_t n, const float *uv, const float *nrm, float *out);
 /* n draws of the device's pcg32 seeded (state, seq): raw 32-bit words (out_u32) or nextFloat() (out_f32), exactly one of the two.
  * Known-answer test entry for ext/pcg32/pcg32-demo.out; Independent::next1D (src/independent.cpp:55-60). */
 int nori_hip_pcg32(NoriHipContext *ctx, uint64_t state, uint64_t seq, size_t n, uint32_t *out_u32, float *out_f32);

@@ -252,7 +252,10 @@ def main():
               # direct_mis (src/directMisIntegrator.cpp) on a subsurface slab with its own IORs
               ("odyssey_ss", S + "/proj/odyssey_ss.xml", 64, 48, 2048, 9),
               # the other path integrator of the reference's tests (src/pathMatsIntegrator.cpp): BSDF sampling only
-              ("cbox_path_mats", S + "/cbox/cbox_path_mats.xml", 64, 64, 2048, 7)]
+              ("cbox_path_mats", S + "/cbox/cbox_path_mats.xml", 64, 64, 2048, 7),
+              # the CPU renderer's procedural textures: checkerboard_color albedos, bump_map over checkerboard_float / constant_float
+              # (src/checkerboard.cpp, src/consttexture.cpp, src/bumpMap.cpp: all compiled into _ref, no OpenCV needed)
+              ("cbox_checker", S + "/cbox/cbox_checker.xml", 64, 64, 4096, 10)]
     for sc in scenes:
         if not only or sc[0] in only:
             scene_fixture(*sc)

@@ -114,7 +114,8 @@ void orc_image_get(void *hp, int si, int k, int *info /*[4]*/, float *xform /*[4
     xform[0] = im.scale.x; xform[1] = im.scale.y; xform[2] = im.delta.x; xform[3] = im.delta.y;
     if (!texels) return;
     const size_t N = (size_t) im.cols * im.rows;
-    if (im.kind == IMG_BUMP) for (size_t i = 0; i < N; ++i) { std::memcpy(texels + 4 * i, &im.gx[i], 2); std::memcpy(texels + 4 * i + 2, &im.gy[i], 2); }
+    if (im.kind == IMG_CHECKER_COLOR || im.kind == IMG_CHECKER_FLOAT) std::memcpy(texels, im.values, N * 4);       // the constants, as the C ABI carries them
+    else if (im.kind == IMG_BUMP) for (size_t i = 0; i < N; ++i) { std::memcpy(texels + 4 * i, &im.gx[i], 2); std::memcpy(texels + 4 * i + 2, &im.gy[i], 2); }
     else std::memcpy(texels, im.rgba.data(), N * 4);
 }
 // albedo image / normal modifier of a shape (-1: none) and its bsdf's subsurface dmfp
@@ -129,7 +130,7 @@ void orc_image_eval(void *hp, int si, int k, int n, const float *uv, const float
     const Image &im = sc->images[k];
     for (int i = 0; i < n; ++i) {
         V2 q = mk2(uv[2 * i], uv[2 * i + 1]);
-        V3 r = im.kind == IMG_COLOR ? image_color(im, q) : image_normal(im, q, Frame(mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2])));
+        V3 r = (im.kind == IMG_COLOR || im.kind == IMG_CHECKER_COLOR) ? image_color(im, q) : image_normal(im, q, Frame(mk3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2])));
         out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
     }
 }

@@ -94,12 +94,28 @@ inline void image_rgba(const Image &im, float cu, float rv, float out[4]) {
     image_lookup(im, cu, rv, [&](int r, int c, float *o) { const uint8_t *p = &im.rgba[((size_t) r * im.cols + c) * 4]; for (int k = 0; k < 4; ++k) o[k] = (float) p[k] / 255.0f; }, out);
 }
 inline float srgb_to_linear(float v) { return v <= 0.04045f ? v * (1.0f / 12.92f) : std::pow((v + 0.055f) * (1.0f / 1.055f), 2.4f); }   // src/common.cpp:208-222
-inline V3 image_color(const Image &im, V2 uv) {           // ImageTexture<Color3f>::eval
+// Checkerboard<T>::eval (src/checkerboard.cpp:32-55): true = value1
+inline bool checker_first(const Image &im, V2 uv) {
+    float x = (uv.x / im.scale.x) - im.delta.x, y = (uv.y / im.scale.y) - im.delta.y;
+    float modx = std::fmod(x, 2.0f), mody = std::fmod(y, 2.0f);
+    if (x < 0) modx = std::fmod(std::fabs(x) + 1, 2.0f);
+    if (y < 0) mody = std::fmod(std::fabs(y) + 1, 2.0f);
+    return (modx <= 1 && mody <= 1) || (modx >= 1 && mody >= 1);
+}
+inline V3 image_color(const Image &im, V2 uv) {           // ImageTexture<Color3f>::eval / Checkerboard<Color3f>::eval
+    if (im.kind == IMG_CHECKER_COLOR) { const float *v = im.values + (checker_first(im, uv) ? 0 : 3); return mk3(v[0], v[1], v[2]); }
     V2 c = image_coords(im, uv); float t[4]; image_rgba(im, c.y, c.x, t);
     if (!im.bilinear) return mk3(t[0], t[1], t[2]);       // CPU variant: no colour-space conversion (src/imagetexture.cpp:49-77)
     return mk3(srgb_to_linear(t[0]), srgb_to_linear(t[1]), srgb_to_linear(t[2]));
 }
 inline V3 image_normal(const Image &im, V2 uv, const Frame &fr) {      // BumpMap::eval / NormalMap::eval
+    // the CPU renderer's bump_map over a Texture<float> (src/bumpMap.cpp:44-50): normal = value, i.e. (v, v, v), as written
+    if (im.kind == IMG_CHECKER_FLOAT) return mk3(im.values[checker_first(im, uv) ? 0 : 1]);
+    if (im.kind == IMG_IMAGE_FLOAT) {                                  // ImageTexture<float>::eval, src/imagetexture.cpp:26-46
+        V2 q = image_coords(im, uv);
+        const int row = (int) (q.x * (float) im.rows), col = (int) (q.y * (float) im.cols);
+        return mk3((float) im.rgba[((size_t) row * im.cols + col) * 4] / 255.0f);
+    }
     V2 c = image_coords(im, uv); float t[4];
     if (im.kind == IMG_BUMP) {
         image_lookup(im, c.x, c.y, [&](int r, int cc, float *o) {
@@ -174,7 +190,12 @@ struct Accel {
     void set_hit_information(uint32_t f, const Ray &ray, Intersection &its) const {
         set_hit_information_base(f, ray, its);
         const Shape &m = scene->shapes[its.shape];
-        if (m.normal_tex >= 0) its.sh = Frame(image_normal(scene->images[m.normal_tex], its.uv, its.sh));   // cuda/nori/mesh.cpp.cu:181-185
+        if (m.normal_tex >= 0) {
+            const Image &im = scene->images[m.normal_tex];
+            // the float kinds are the CPU renderer's modifier: meshes with vertex normals only (src/mesh.cpp:151-164)
+            const bool cpu_kind = im.kind == IMG_CHECKER_FLOAT || im.kind == IMG_IMAGE_FLOAT;
+            if (!cpu_kind || (m.type == SHAPE_MESH && !m.N.empty())) its.sh = Frame(image_normal(im, its.uv, its.sh));   // cuda/nori/mesh.cpp.cu:181-185
+        }
     }
     void set_hit_information_base(uint32_t f, const Ray &ray, Intersection &its) const {
         const Shape &m = scene->shapes[its.shape];

@@ -60,6 +60,7 @@ struct Props {
     int geti(const char *k, int d) const { auto it = i.find(k); return it == i.end() ? d : it->second; }
     V3 getv(const char *k, V3 d) const { auto it = v.find(k); return it == v.end() ? d : it->second; }
     bool hasv(const char *k) const { return v.count(k) != 0; }
+    bool hass(const char *k) const { return s.count(k) != 0; }
     std::string gets(const char *k) const { auto it = s.find(k); if (it == s.end()) throw std::runtime_error(std::string("Property '") + k + "' is missing!"); return it->second; }
     std::string gets(const char *k, const std::string &d) const { auto it = s.find(k); return it == s.end() ? d : it->second; }
     Transform gett(const char *k) const { auto it = t.find(k); return it == t.end() ? Transform() : it->second; }
@@ -76,9 +77,11 @@ struct Bsdf {
     V3 dmfp = mk3(0.1f);                   // subsurface (src/subsurface.cpp:44-46); s = 1 (:91)
 };
 // An image as the CUDA fork uploads it: RGBA bytes (colour, normal map) or the two 16-bit Sobel gradients (bump map)
-enum ImageKind { IMG_COLOR = 0, IMG_BUMP = 1, IMG_NORMAL = 2 };
+// ... or one of the CPU renderer's procedural / scalar textures (src/checkerboard.cpp, src/consttexture.cpp, src/imagetexture.cpp:26-46)
+enum ImageKind { IMG_COLOR = 0, IMG_BUMP = 1, IMG_NORMAL = 2, IMG_CHECKER_COLOR = 3, IMG_CHECKER_FLOAT = 4, IMG_IMAGE_FLOAT = 5 };
 struct Image {
     int kind = IMG_COLOR; bool bilinear = true;
+    float values[6] = {0, 0, 0, 0, 0, 0};  // IMG_CHECKER_COLOR: value1 rgb, value2 rgb; IMG_CHECKER_FLOAT: value1, value2
     int cols = 0, rows = 0;
     std::vector<uint8_t> rgba;             // IMG_COLOR / IMG_NORMAL: 4 per texel
     std::vector<int16_t> gx, gy;           // IMG_BUMP
@@ -351,6 +354,14 @@ inline Image load_image(const XmlNode &n, const std::string &dir, int kind) {
     im.bilinear = pl.gets("lookup", "bilinear") != "nearest";
     int ch; std::vector<uint8_t> px; load_image_file(dir + "/" + pl.gets("filename"), im.cols, im.rows, ch, px);
     const size_t N = (size_t) im.cols * im.rows;
+    if (kind == IMG_IMAGE_FLOAT) {          // cv::imread(..., GRAYSCALE): fixed-point BT.601 luma of a colour file
+        im.rgba.resize(N * 4);
+        for (size_t i = 0; i < N; ++i) {
+            const uint8_t g = ch == 1 ? px[i] : (uint8_t) ((px[3 * i] * 4899 + px[3 * i + 1] * 9617 + px[3 * i + 2] * 1868 + 8192) >> 14);
+            im.rgba[4 * i] = im.rgba[4 * i + 1] = im.rgba[4 * i + 2] = g; im.rgba[4 * i + 3] = 255;
+        }
+        return im;
+    }
     if (kind != IMG_BUMP) {
         im.rgba.resize(N * 4);
         for (size_t i = 0; i < N; ++i) for (int c = 0; c < 4; ++c) im.rgba[4 * i + c] = c == 3 ? 255 : (ch == 3 ? px[3 * i + c] : px[i]);
@@ -372,6 +383,20 @@ inline Image load_image(const XmlNode &n, const std::string &dir, int kind) {
     return im;
 }
 
+// checkerboard_color / checkerboard_float / constant_float (src/checkerboard.cpp:65-79, src/consttexture.cpp:38-41)
+inline Image load_procedural(const XmlNode &n, int kind, bool constant) {
+    Props pl; parse_props(n, pl);
+    Image im; im.kind = kind; im.bilinear = false; im.delta = pl.getv2("delta", mk2(0.f, 0.f)); im.scale = pl.getv2("scale", mk2(1.f, 1.f));
+    if (kind == IMG_CHECKER_COLOR) {
+        V3 a = pl.getv("value1", mk3(0.f)), b = pl.getv("value2", mk3(1.f));
+        const float v[6] = {a.x, a.y, a.z, b.x, b.y, b.z}; for (int k = 0; k < 6; ++k) im.values[k] = v[k];
+        im.cols = 6; im.rows = 1;
+    } else {
+        im.values[0] = constant ? pl.getf("value", 0.f) : pl.getf("value1", 0.f); im.values[1] = constant ? im.values[0] : pl.getf("value2", 1.f);
+        im.cols = 2; im.rows = 1;
+    }
+    return im;
+}
 inline Bsdf parse_bsdf(const XmlNode &n, const std::string &dir, std::vector<Image> &images) {
     Props pl; parse_props(n, pl);
     Bsdf b; std::string type = n.attr("type");
@@ -383,6 +408,7 @@ inline Bsdf parse_bsdf(const XmlNode &n, const std::string &dir, std::vector<Ima
             has = true; std::string tt = ch->attr("type");
             if (tt == "constant_color") { Props tp; parse_props(*ch, tp); b.albedo = tp.getv("value", mk3(0.f)); }
             else if (tt == "image_color") { b.albedo_tex = (int) images.size(); images.push_back(load_image(*ch, dir, IMG_COLOR)); }
+            else if (tt == "checkerboard_color") { b.albedo_tex = (int) images.size(); images.push_back(load_procedural(*ch, IMG_CHECKER_COLOR, false)); }
             else throw std::runtime_error("oracle: unsupported texture type \"" + tt + "\"");
         }
     };
@@ -430,7 +456,25 @@ inline Scene parse_scene(const XmlNode &node, const std::string &dir) {
                     if (sh.normal_tex >= 0) throw std::runtime_error("Shape: tried to register multiple Normal modifier instances!");
                     std::string mt = sub->attr("type");
                     if (mt != "bump_map" && mt != "normal_map") throw std::runtime_error("oracle: unsupported normalModifier type \"" + mt + "\"");
+                    Props mp; parse_props(*sub, mp);
+                    if (mt == "bump_map" && !mp.hass("filename")) {
+                        // the CPU renderer's bump_map (src/bumpMap.cpp): a Texture<float> child named "bump_map"
+                        const XmlNode *tex = nullptr;
+                        for (auto &tc : sub->children) if (tc->name == "texture") {
+                            if (std::string(tc->attr("name")) != "bump_map") throw std::runtime_error("The name of this texture does not match any field!");
+                            if (tex) throw std::runtime_error("There is already an bump_map defined!");
+                            tex = tc.get();
+                        }
+                        if (!tex) throw std::runtime_error("There is no texture with name bump_map given!");
+                        const std::string tt = tex->attr("type");
+                        sh.normal_tex = (int) sc.images.size();
+                        if (tt == "checkerboard_float") sc.images.push_back(load_procedural(*tex, IMG_CHECKER_FLOAT, false));
+                        else if (tt == "constant_float") sc.images.push_back(load_procedural(*tex, IMG_CHECKER_FLOAT, true));
+                        else if (tt == "image_float") { Image im = load_image(*tex, dir, IMG_IMAGE_FLOAT); im.bilinear = false; sc.images.push_back(im); }
+                        else throw std::runtime_error("oracle: unsupported float texture type \"" + tt + "\"");
+                    } else {
                     sh.normal_tex = (int) sc.images.size(); sc.images.push_back(load_image(*sub, dir, mt == "bump_map" ? IMG_BUMP : IMG_NORMAL));
+                    }
                 }
                 else if (sub->name == "emitter") {
                     if (is_emitter) throw std::runtime_error("Shape: tried to register multiple Emitter instances!");

@@ -58,11 +58,7 @@ def test_c4_reduced_hits_and_li_against_oracle_with_the_reference_order_tree(c4_
     st = np.arange(n, dtype=np.uint64)
     li = ctx.li_samples(st, np.zeros(n, np.uint64), rays=rays[:n])
     oli = o.li_rays(rays[:n], st, np.zeros(n, np.uint64))
-    err = np.abs(li - oli).max(1) / np.maximum(np.abs(oli).max(1), 1e-3)
-    assert (err < 1e-3).mean() > 0.97, (err < 1e-3).mean()
-    bad = err >= 1e-3
-    # the samples that branch differently (device libm ulps at a comparison) are bounded in what they contribute to the mean
-    assert np.abs((li[bad] - oli[bad]).sum(0)).max() / n < 5e-3 * max(oli.mean(), 1e-6)
+    assert np.array_equal(li, oli)         # a diffuse scene, the reference-order tree: every sample's Li bit for bit (nd_sincosf, csrc/nori_device.h)
     # image at matched streams
     ctx.clear_film(); ctx.reset_stats(); ctx.render(0, 4)
     img, film = ctx.read_bitmap(), ctx.read_film()
@@ -191,7 +187,10 @@ def test_c4_full_size_hits_and_li_against_the_oracle(tmp_path):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         open(os.path.join(out, "c4_full_size_parity.txt"), "w").write(msg + "\n")
-    assert (err < 1e-3).mean() > 0.95, (err < 1e-3).mean()
-    assert abs(li.mean() - oli.mean()) < 0.03 * oli.mean()
+    # device-built tree: another primitive can win a tie in t (a shared edge), and that sample's path differs from there on; all others
+    # are the oracle's bit for bit (round 2: 0.9985 within 1e-3, 0.78 bit-identical)
+    assert (li == oli).all(1).mean() > 0.995, (li == oli).all(1).mean()
+    assert (err < 1e-3).mean() > 0.995, (err < 1e-3).mean()
+    assert abs(li.mean() - oli.mean()) < 0.01 * oli.mean()
     hs.close()
 

@@ -12,7 +12,7 @@ import oracle_lib as O
 from conftest import ROOT, SCENES
 
 XMLS = ["cbox/cbox_path_mis.xml", "cbox/cbox_mirror_microfacet.xml", "table/table_path_mis.xml", "table/table_path_mis_microfacet.xml", "proj/dragon-diffuse.xml",
-        "proj/cbox_subsurface.xml", "proj/textureAndBump.xml", "proj/normal.xml"]
+        "proj/cbox_subsurface.xml", "proj/textureAndBump.xml", "proj/normal.xml", "cbox/cbox_checker.xml"]
 
 
 def test_c_abi_exports_every_declared_symbol():
@@ -81,7 +81,7 @@ def test_flattened_tables_are_consistent():
     assert np.array_equal(prims["a"], shade["p0"]) and np.array_equal(prims["e1"], shade["p1"] - shade["p0"])
 
 
-@pytest.mark.parametrize("xml", ["proj/textureAndBump.xml", "proj/normal.xml", "proj/cbox_subsurface.xml"])
+@pytest.mark.parametrize("xml", ["proj/textureAndBump.xml", "proj/normal.xml", "proj/cbox_subsurface.xml", "cbox/cbox_checker.xml"])
 def test_images_and_subsurface_parameters_flatten_like_the_oracle(xml):
     """image tables (kind, size, uv transform, texels incl. the Sobel gradients of bump maps) and the per-shape
     texture / modifier / subsurface fields: host plugins vs the oracle's independent restatement"""
@@ -126,6 +126,29 @@ def test_texture_plugins_report_errors_like_the_reference(tmp_path):
         load(mod + mod)
     with pytest.raises(NH.NoriHipError, match="not of size 2 or 3"):
         load('<normalModifier type="bump_map"><string name="filename" value="g.pgm"/><vector name="scale" value="1"/></normalModifier>')
+    # the CPU renderer's bump_map takes a Texture<float> child (src/bumpMap.cpp:19-42); the texture kinds must fit their slot
+    with pytest.raises(NH.NoriHipError, match="no texture with name bump_map"):
+        load('<normalModifier type="bump_map"/>')
+    with pytest.raises(NH.NoriHipError, match="does not match any field"):
+        load('<normalModifier type="bump_map"><texture type="constant_float" name="height"/></normalModifier>')
+    with pytest.raises(NH.NoriHipError, match="must be a float texture"):
+        load('<normalModifier type="bump_map"><texture type="checkerboard_color" name="bump_map"/></normalModifier>')
+    with pytest.raises(NH.NoriHipError, match="must be a colour texture"):
+        load('<bsdf type="diffuse"><texture type="checkerboard_float" name="albedo"/></bsdf>')
+    hs = load('<bsdf type="diffuse"><texture type="checkerboard_color" name="albedo"><color name="value2" value="0.25 0.5 0.75"/><vector name="scale" value="0.5,0.25"/></texture></bsdf>'
+              '<normalModifier type="bump_map"><texture type="image_float" name="bump_map"><string name="filename" value="g.pgm"/></texture></normalModifier>')
+    T = hs.tables()
+    t0, t1 = T["textures"]
+    assert (t0["kind"], t0["width"], t0["height"]) == (3, 6, 1) and t0["scale"].tolist() == [0.5, 0.25]
+    assert T["tex_data"][int(t0["offset"]):int(t0["offset"]) + 24].view(np.float32).tolist() == [0, 0, 0, 0.25, 0.5, 0.75]     # value1 defaults to 0 (src/checkerboard.cpp:77)
+    assert (t1["kind"], t1["width"], t1["height"]) == (5, 2, 2)
+    assert T["tex_data"][int(t1["offset"]):int(t1["offset"]) + 16].reshape(4, 4)[:, 0].tolist() == [0, 64, 128, 255]
+    o = O.OracleScene(str(tmp_path / "s.xml"))
+    ims = o.images()
+    assert [m["kind"] for m in ims] == [3, 5] and np.array_equal(ims[1]["texels"], T["tex_data"][int(t1["offset"]):int(t1["offset"]) + 16])
+    # ImageTexture<float>::eval (src/imagetexture.cpp:26-46): row = x * rows, col = y * cols, value / 255 -> the normal (v, v, v)
+    got = o.image_eval(1, np.array([[0.1, 0.1], [0.1, 0.6], [0.6, 0.1], [0.9, 0.9], [1.75, -0.25]], np.float32), np.zeros((5, 3), np.float32) + [0, 0, 1])
+    assert np.array_equal(got[:, 0], (np.array([0, 64, 128, 255, 255], np.float32) / np.float32(255))) and np.all(got[:, 0:1] == got)
     hs = load(mod.replace("</normalModifier>", '<vector name="scale" value="2,4"/><point name="delta" value="0.5,0.25"/></normalModifier>'))
     t = hs.tables()["textures"][0]
     assert (t["kind"], t["width"], t["height"]) == (1, 2, 2) and t["scale"].tolist() == [2.0, 4.0] and t["delta"].tolist() == [0.5, 0.25]

@@ -19,6 +19,7 @@ SCENE_XML = {
     "dragon_ss": "proj/dragon-ss.xml",                   # subsurface dragon: masked probes through the deep tree
     "odyssey_ss": "proj/odyssey_ss.xml",                 # direct_mis integrator on a subsurface slab with its own IORs
     "cbox_path_mats": "cbox/cbox_path_mats.xml",         # the other path integrator (src/pathMatsIntegrator.cpp)
+    "cbox_checker": "cbox/cbox_checker.xml",             # checkerboard_color albedos, bump_map over checkerboard_float / constant_float (CPU plugins)
 }
 
 
