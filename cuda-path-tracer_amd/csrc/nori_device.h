@@ -196,6 +196,7 @@ struct DevScene {
                                        // bit 1 set (default): any-hit rays enter the nearer child first whatever bit 0 says (same answer for every order)
     int cull_zero;                     // emitter samples whose term is exactly zero get no shadow ray (shade_finish)
     int prim_lanes;                    // run-to-completion traversal: lanes that must wait at a leaf before a record step is issued
+    int leaf2;                         // leaves hold at most two records, placed inside one 128-byte line (Trav::prim_step2 may be used)
     uint32_t n_top;                    // nodes [0, n_top) are the top of the tree in breadth-first order (LDS cache candidates)
     float root_min[3], root_max[3];
     NoriHipCamera cam;
@@ -536,6 +537,19 @@ template <bool ANY> struct Trav {
         if (mask == 0xffffffffu || (fl & 0xffffffu) == mask) { prim_compute(A, B, C, n_prims, any); return true; }
         cur = (fl & 0x80000000u) ? ND_POP : (NORI_HIP_LEAF_BIT | ((cur & 0x7fffffffu) + 1u));
         return false;
+    }
+    // Both records of a leaf in ONE step, for trees whose leaves hold at most two records placed inside one 128-byte line (device-built
+    // trees of a million records or more: lbvh `align_leaves`): the six 16-byte loads of the line are issued together and the lane
+    // waits for memory once per leaf instead of once per record.  The second record is tested after the first with the maxt the first
+    // left behind, exactly as two single steps would, so hits and the count of record tests are unchanged.  Returns whether the second
+    // record was tested (statistics).  (The position after the last record of the array exists: the placement pads to eight.)
+    __device__ __forceinline__ bool prim_step2(const DevScene &sc, uint32_t &n_prims, const bool any) {
+        const float4 *r = sc.prims + 3 * (size_t) (cur & 0x7fffffffu);
+        const float4 A0 = r[0], B0 = r[1], C0 = r[2], A1 = r[3], B1 = r[4], C1 = r[5];
+        prim_compute(A0, B0, C0, n_prims, any);
+        const bool second = at_leaf();
+        if (second) prim_compute(A1, B1, C1, n_prims, any);
+        return second;
     }
     __device__ __forceinline__ void prim_fetch(const DevScene &sc, float4 &A, float4 &B, float4 &C) const {
         const float4 *r = sc.prims + 3 * (size_t) (cur & 0x7fffffffu);

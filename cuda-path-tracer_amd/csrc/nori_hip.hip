@@ -678,7 +678,8 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 #endif
 // MASKED (scenes with subsurface shapes): an extend ray whose slot holds ND_PROBE_MARK is a probe, a closest-hit query restricted
 // to the records of one shape (BVH::rayIntersect's mask, src/bvh.cpp:438).
-template <int KIND, bool PROF, bool SPEC, int WIDE, bool MASKED = false>
+// PRIM2: a lane at a leaf tests both records of the leaf in one trip (Trav::prim_step2; leaves of at most two records inside one line)
+template <int KIND, bool PROF, bool SPEC, int WIDE, bool MASKED = false, bool PRIM2 = false>
 __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
     constexpr int DEPTH = WIDE == 8 ? TRACE_DEPTH_W8 : WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
@@ -867,6 +868,10 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
                     bool tested = false;
                     if (tv.at_leaf()) tested = tv.prim_step_masked(sc, dummy, (KIND == TK_BOTH) ? any : ANY, mask);
                     n_prims += (unsigned int) __popcll(__ballot(tested));
+                } else if (PRIM2) {
+                    bool second = false;
+                    if (tv.at_leaf()) second = tv.prim_step2(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
+                    n_prims += (unsigned int) __popcll(m_lf) + (unsigned int) __popcll(__ballot(second));
                 } else {
                     n_prims += (unsigned int) __popcll(m_lf);
                     if (tv.at_leaf()) tv.prim_step(sc, dummy, (KIND == TK_BOTH) ? any : ANY);
@@ -940,6 +945,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WA
 template <bool PROF, bool SPEC>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
     trace_pool_body<TK_BOTH, PROF, SPEC, 4>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
+}
+// ... with both records of a leaf tested in one trip (device-built trees whose leaves are placed inside lines; no speculation)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4_leaf2(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
+    trace_pool_body<TK_BOTH, false, false, 4, false, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
 }
 // ... over quantised eight-box nodes (device-built trees that do not fit the caches)
 #ifndef ND_WIDE8_WAVES
@@ -1379,6 +1388,7 @@ struct NoriHipContext {
     int trace_threads = 256;          // workgroup size of the trace stages (NORI_HIP_TRACE_THREADS: 256, 512, 768 or 1024)
     float *scratch_ptr = nullptr;     // this device's copy of `scratch` (nori_hip_filter_noalloc)
     size_t trace_lds = 0;             // dynamic LDS of a trace-stage workgroup (set once, with the kernels' attribute, in nori_hip_create)
+    bool leaf2_step = true;           // NORI_HIP_LEAF2=0: one record per trip also where the leaves would allow two (Trav::prim_step2)
     int spec = -1;                    // NORI_HIP_SPEC: 1 / 0 = speculative traversal in the merged trace stage or not; -1 = unless the tree does not fit the
                                       // caches (there the stage waits for HBM lines, and the extra boxes that speculation lets pass cost more than the waiting it saves)
     int xcd_chunks = -1;              // NORI_HIP_XCD: chunks of the sorted ray order per XCD in the trace stage's deal (0 = off, -1 = 64)
@@ -1457,6 +1467,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_LBVH_MORTON")) c->lbvh_plain = std::string(e) == "plain";
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
+    if (const char *e = getenv("NORI_HIP_LEAF2")) c->leaf2_step = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_WIDE")) { const int v = atoi(e); c->wide = v != 0; c->wide8 = v == 8 ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
     if (const char *e = getenv("NORI_HIP_KEYS")) c->fused_keys = std::string(e) != "kernel";
@@ -1503,6 +1514,7 @@ static int create_impl(NoriHipContext *c, int device) {
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool<TK_EXTEND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds));
     c->trace_lds_wide = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH_W * 64 * 8 + 64 * 52);
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4_masked, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
@@ -1741,6 +1753,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
     // a device-built tree has no reference child order to keep: the nearer child is entered first
     sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u; sc.nodes8 = ctx->d_nodes8;
+    sc.leaf2 = (device_build && n_records != d->n_prims) ? 1 : 0;            // (the placed layout: lbvh::Result::prims_al was taken over above)
     sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.cull_zero = ctx->cull_zero ? 1 : 0; {
         const size_t tree_b = (size_t) (ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
         const bool far = ctx->any_far >= 0 ? ctx->any_far != 0 : tree_b > ((size_t) 192 << 20);
@@ -2121,6 +2134,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
                     void (*k8)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *, const unsigned int *) =
                         ctx->profile ? (spec ? k_trace_pool8<true, true> : k_trace_pool8<true, false>) : (spec ? k_trace_pool8<false, true> : k_trace_pool8<false, false>);
                     hipLaunchKernelGGL(k8, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
+                } else if (wide && !spec && !ctx->profile && ctx->sc.leaf2 && ctx->leaf2_step) {
+                    hipLaunchKernelGGL(k_trace_pool4_leaf2, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
                 } else if (wide) {
                     void (*k4)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *, const unsigned int *) =
                         ctx->profile ? (spec ? k_trace_pool4<true, true> : k_trace_pool4<true, false>) : (spec ? k_trace_pool4<false, true> : k_trace_pool4<false, false>);
