@@ -159,6 +159,46 @@ void BVH::build(int threads) {
         if (n < 100000 || threads == 1) work(0, n);
         else { std::vector<std::thread> th; for (int t = 0; t < threads; ++t) th.emplace_back(work, (uint32_t) ((uint64_t) n * t / threads), (uint32_t) ((uint64_t) n * (t + 1) / threads)); for (auto &t : th) t.join(); }
     }
+    // On-disk cache of the tree ($NORI_HIP_BVH_CACHE = a directory): the reference-order SAH build is a function
+    // of the per-primitive boxes and centroids just tabulated (and of the scene box), so their 64-bit hash names the entry; a hit
+    // replaces 14 s of building for ten million triangles by a read.  An entry is used only if its key, counts and sizes agree and
+    // every index is in range; nori_hip_upload_scene checks the structure of whatever tree it is given before a kernel walks it.
+    std::string cachePath; uint64_t cacheKey = 0;
+    if (const char *cdir = getenv("NORI_HIP_BVH_CACHE")) if (*cdir) {
+        // (hashed in fixed chunks of 65536 primitives, combined in order: the key does not depend on the number of threads)
+        const uint32_t n_chunks = (n + 65535u) / 65536u;
+        std::vector<uint64_t> part((size_t) n_chunks, 0);
+        auto hashChunks = [&](uint32_t c0, uint32_t c1) {
+            for (uint32_t c = c0; c < c1; ++c) {
+                uint64_t h = 0x9E3779B97F4A7C15ull ^ c;
+                auto mix = [&](const void *p, size_t bytes) { const uint32_t *w = (const uint32_t *) p; for (size_t k = 0; k < bytes / 4; ++k) { h ^= w[k]; h *= 0x100000001B3ull; h ^= h >> 29; } };
+                const uint32_t hi = std::min<uint64_t>(n, ((uint64_t) c + 1) * 65536u);
+                for (uint32_t i = c * 65536u; i < hi; ++i) { mix(&b.box[i], sizeof(BoundingBox3f)); const float c3[3] = {b.c[0][i], b.c[1][i], b.c[2][i]}; mix(c3, 12); }
+                part[c] = h;
+            }
+        };
+        { std::vector<std::thread> th; for (int t = 0; t < threads; ++t) th.emplace_back(hashChunks, (uint32_t) ((uint64_t) n_chunks * t / threads), (uint32_t) ((uint64_t) n_chunks * (t + 1) / threads)); for (auto &t : th) t.join(); }
+        uint64_t h = 0xCBF29CE484222325ull ^ n;
+        for (uint64_t v : part) { h ^= v; h *= 0x100000001B3ull; h ^= h >> 31; }
+        const float bb[6] = {m_bbox.min[0], m_bbox.min[1], m_bbox.min[2], m_bbox.max[0], m_bbox.max[1], m_bbox.max[2]};
+        for (float f : bb) { uint32_t w; std::memcpy(&w, &f, 4); h ^= w; h *= 0x100000001B3ull; h ^= h >> 31; }
+        cacheKey = h;
+        char name[64]; snprintf(name, sizeof(name), "/bvh-%016llx.noricache", (unsigned long long) h);
+        cachePath = std::string(cdir) + name;
+        struct Hdr { char magic[8]; uint64_t key; uint32_t n, nNodes; } hd;
+        FILE *f = fopen(cachePath.c_str(), "rb");
+        if (f) {
+            bool ok = fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, "NORIBVH1", 8) == 0 && hd.key == h && hd.n == n && hd.nNodes >= 1 && hd.nNodes <= 2u * n;
+            if (ok) {
+                m_nodes.resize(hd.nNodes); m_indices.resize(n);
+                ok = fread(m_nodes.data(), sizeof(Node32), hd.nNodes, f) == hd.nNodes && fread(m_indices.data(), 4, n, f) == n && fgetc(f) == EOF;
+                for (uint32_t i = 0; ok && i < n; ++i) ok = m_indices[i] < n;
+            }
+            fclose(f);
+            if (ok) { m_buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); return; }
+            m_nodes.clear(); m_indices.clear();
+        }
+    }
     m_indices.resize(n);
     for (uint32_t i = 0; i < n; ++i) m_indices[i] = i;
     std::vector<uint32_t> temp(n);
@@ -167,6 +207,15 @@ void BVH::build(int threads) {
     b.split(m_nodes, m_bbox, 0, n, threads);
     m_nodes.shrink_to_fit();
     m_buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!cachePath.empty()) {
+        struct Hdr { char magic[8]; uint64_t key; uint32_t n, nNodes; } hd;
+        std::memcpy(hd.magic, "NORIBVH1", 8); hd.key = cacheKey; hd.n = n; hd.nNodes = (uint32_t) m_nodes.size();
+        const std::string tmp = cachePath + ".tmp";
+        if (FILE *f = fopen(tmp.c_str(), "wb")) {                      // (a directory that cannot be written: no entry, no error)
+            const bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1 && fwrite(m_nodes.data(), sizeof(Node32), m_nodes.size(), f) == m_nodes.size() && fwrite(m_indices.data(), 4, n, f) == n;
+            if (fclose(f) == 0 && ok) std::rename(tmp.c_str(), cachePath.c_str()); else std::remove(tmp.c_str());
+        }
+    }
 }
 
 // ---- flattening -------------------------------------------------------------------------------------------

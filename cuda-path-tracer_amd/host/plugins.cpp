@@ -2,10 +2,8 @@
 // Reference: src/obj.cpp, src/mesh.cpp, src/sphere.cpp, src/shape.cpp, src/diffuse.cpp, src/microfacet.cpp,
 //            src/dielectric.cpp, src/mirror.cpp, src/arealight.cpp, src/perspective.cpp, src/independent.cpp,
 //            src/rfilter.cpp, src/scene.cpp, src/consttexture.cpp.
-// Derivative text: the OBJ loader below (WavefrontOBJ's constructor) follows src/obj.cpp:32-125 statement by statement — the
-// order in which vertices are first seen, the (p, uv, n) de-duplication key and its hash decide the vertex numbering, which the
-// parity tests compare with the reference's loader output — so it keeps that function's structure and names.  Everything
-// else in this file (mesh cache, PNM reader, Sobel gradients, the plugins' describe()) has no counterpart there.
+// The OBJ reader itself is host/objreader.cpp (mapped file, parsed in parallel pieces, vertex numbers by first use): its OUTPUT is
+// what src/obj.cpp:32-132 produces - the parity tests compare the arrays - its text is not that function's.
 #include "scene.h"
 #include <cstring>
 #include <cstdio>
@@ -67,14 +65,13 @@ std::string Mesh::toString() const {
     return buf;
 }
 
-/// Wavefront OBJ loader (src/obj.cpp:32-132): v/vt/vn/f, toWorld applied at load, quads split (0,1,2),(3,0,2),
-/// vertices de-duplicated on the (p, uv, n) index triple in order of first use.
+/// Wavefront OBJ mesh (src/obj.cpp:32-132): v/vt/vn/f, toWorld applied at load, quads split (0,1,2),(3,0,2),
+/// vertices de-duplicated on the (p, uv, n) index triple in order of first use - read by readWavefrontOBJ (host/objreader.cpp).
 class WavefrontOBJ : public Mesh {
 public:
     explicit WavefrontOBJ(const PropertyList &propList) {
         std::string filename = getFileResolver()->resolve(propList.getString("filename"));
-        std::ifstream is(filename);
-        if (is.fail()) throw NoriException::format("Unable to open OBJ file \"%s\"!", filename.c_str());
+        { std::ifstream is(filename); if (is.fail()) throw NoriException::format("Unable to open OBJ file \"%s\"!", filename.c_str()); }
         Transform trafo = propList.getTransform("toWorld", Transform());
         // Binary cache of the parsed, transformed, de-duplicated arrays (text-parsing a 10 M-triangle OBJ
         // dominates start-up).  Opt-in: $NORI_HIP_MESH_CACHE=1 reads and writes "<file>.noricache" next to the OBJ; an entry
@@ -82,44 +79,7 @@ public:
         const char *cenv = getenv("NORI_HIP_MESH_CACHE");
         const bool useCache = cenv && atoi(cenv) != 0;
         if (useCache && loadCache(filename, trafo)) { m_name = filename; return; }
-        struct Key { uint32_t p, n, uv; bool operator==(const Key &o) const { return p == o.p && n == o.n && uv == o.uv; } };
-        struct KeyHash { size_t operator()(const Key &k) const { size_t h = k.p; h = h * 37 + k.uv; h = h * 37 + k.n; return h; } };
-        std::vector<Point3f> positions, normals; std::vector<Point2f> texcoords; std::vector<Key> vertices;
-        std::unordered_map<Key, uint32_t, KeyHash> vertexMap;
-        auto parseVertex = [](const std::string &s) {
-            std::vector<std::string> tk = tokenize(s, "/", true);
-            if (tk.size() < 1 || tk.size() > 3) throw NoriException::format("Invalid vertex data: \"%s\"", s.c_str());
-            Key k{(uint32_t) -1, (uint32_t) -1, (uint32_t) -1};
-            k.p = toUInt(tk[0]);
-            if (tk.size() >= 2 && !tk[1].empty()) k.uv = toUInt(tk[1]);
-            if (tk.size() >= 3 && !tk[2].empty()) k.n = toUInt(tk[2]);
-            return k;
-        };
-        std::string line_str;
-        while (std::getline(is, line_str)) {
-            std::istringstream line(line_str);
-            std::string prefix; line >> prefix;
-            if (prefix == "v") { Point3f p; line >> p.x >> p.y >> p.z; p = trafo.point(p); m_bbox.expandBy(p); positions.push_back(p); }
-            else if (prefix == "vt") { Point2f tc; line >> tc.x >> tc.y; texcoords.push_back(tc); }
-            else if (prefix == "vn") { Normal3f n; line >> n.x >> n.y >> n.z; normals.push_back(normalized(trafo.normal(n))); }
-            else if (prefix == "f") {
-                std::string v[4]; line >> v[0] >> v[1] >> v[2] >> v[3];
-                Key verts[6]; int nV = 3;
-                for (int i = 0; i < 3; ++i) verts[i] = parseVertex(v[i]);
-                if (!v[3].empty()) { verts[3] = parseVertex(v[3]); verts[4] = verts[0]; verts[5] = verts[2]; nV = 6; }
-                for (int i = 0; i < nV; ++i) {
-                    auto it = vertexMap.find(verts[i]);
-                    if (it == vertexMap.end()) { uint32_t id = (uint32_t) vertices.size(); vertexMap[verts[i]] = id; m_F.push_back(id); vertices.push_back(verts[i]); }
-                    else m_F.push_back(it->second);
-                }
-            }
-        }
-        m_V.resize(3 * vertices.size());
-        for (size_t i = 0; i < vertices.size(); ++i) { const Point3f &p = positions.at(vertices[i].p - 1); m_V[3 * i] = p.x; m_V[3 * i + 1] = p.y; m_V[3 * i + 2] = p.z; }
-        if (!normals.empty()) { m_N.resize(3 * vertices.size());
-            for (size_t i = 0; i < vertices.size(); ++i) { const Normal3f &n = normals.at(vertices[i].n - 1); m_N[3 * i] = n.x; m_N[3 * i + 1] = n.y; m_N[3 * i + 2] = n.z; } }
-        if (!texcoords.empty()) { m_UV.resize(2 * vertices.size());
-            for (size_t i = 0; i < vertices.size(); ++i) { const Point2f &t = texcoords.at(vertices[i].uv - 1); m_UV[2 * i] = t.x; m_UV[2 * i + 1] = t.y; } }
+        readWavefrontOBJ(filename, trafo, m_V, m_N, m_UV, m_F, m_bbox);      // host/objreader.cpp
         m_name = filename;
         if (useCache) saveCache(filename, trafo);
     }

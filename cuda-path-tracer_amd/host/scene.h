@@ -17,6 +17,10 @@ struct ImageData { NoriHipTexture meta; std::vector<uint8_t> texels; };
 /// "<file>.pgm" is read instead (the reference decodes with cv::imread, which this build does not have).
 /// Returns rows x cols x channels bytes, channels = 1 or 3 (RGB order).
 void loadImageFile(const std::string &filename, int &cols, int &rows, int &channels, std::vector<uint8_t> &data);
+/// Reads a Wavefront OBJ file into the arrays Mesh holds (host/objreader.cpp): V 3 per vertex, N / UV if the file has them, F 3 per
+/// triangle; vertex numbering, quad split, toWorld and de-duplication as src/obj.cpp:32-132 produces them.
+void readWavefrontOBJ(const std::string &filename, const Transform &trafo, std::vector<float> &V, std::vector<float> &N, std::vector<float> &UV,
+                      std::vector<uint32_t> &F, BoundingBox3f &bbox);
 
 /// Texture<Color3f> (include/nori/texture.h): a constant colour or an image
 class ColorTexture : public NoriObject {

@@ -3,6 +3,7 @@ C ABI's exported symbols.  No kernel is launched here."""
 import ctypes as C
 import os
 import re
+import shutil
 
 import numpy as np
 import pytest
@@ -210,6 +211,83 @@ def test_procedural_scene_builder_and_parallel_bvh_build_is_deterministic():
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+def test_obj_reader_equals_the_reference_loader_on_awkward_files(tmp_path):
+    """host/objreader.cpp (mapped file, parallel pieces, vertex numbers by first use) against the oracle's loader, which is
+    bit-identical to the reference's (src/obj.cpp:32-132, oracle/make_golden.py): quads, every face-token form, CRLF, tabs, signs,
+    exponents, numbers that need more than a double to round correctly, a file long enough to be cut into several pieces."""
+    rng = np.random.default_rng(17)
+    nv = 60000
+    fmts = ["%.9g", "%.6f", "%.17g", "%e", "%.3f", "%+.8g", "%.12e", "%.25f"]
+    rows, want = [], []
+    for i in range(nv):
+        v = rng.normal(size=3) * 10.0 ** rng.integers(-6, 6)
+        if i % 1000 == 0:                       # halfway cases between two floats: the text is a float midpoint, exactly or off by one digit in the 40th place
+            f0 = np.float32(v[0]); mid = (np.float64(f0) + np.float64(np.nextafter(f0, np.float32(np.inf)))) / 2
+            txt = ["%.60g" % mid, "%.60g1" % mid if "." in "%.60g" % mid else "%.60g.0001" % mid, fmts[i % len(fmts)] % v[2]]
+        else:
+            txt = [fmts[(i + k) % len(fmts)] % v[k] for k in range(3)]
+        rows.append("v" + ("\t" if i % 7 == 0 else " ") + "  ".join(txt) + ("\r" if i % 3 == 0 else ""))
+        want.append(txt)
+    lines = ["# awkward", "o thing", "s off"] + rows
+    lines += ["vt %.7g %.7g" % tuple(rng.random(2)) for _ in range(nv)] + ["vn %.7g %.7g %.7g" % tuple(rng.normal(size=3)) for _ in range(nv)]
+    faces = []
+    for k in range(90000):
+        a, b, c, d = (int(x) + 1 for x in rng.integers(0, nv, 4))
+        form = k % 4
+        tok = (lambda i: "%d/%d/%d" % (i, (i * 7) % nv + 1, i)) if form == 0 else (lambda i: "%d/%d/%d" % (i, i, (i * 3) % nv + 1)) if form == 1 else (lambda i: "%d/%d/%d" % (i, i, i))
+        faces.append("f " + " ".join(tok(i) for i in ((a, b, c, d) if k % 5 == 0 else (a, b, c))) + ("  " if k % 11 == 0 else ""))
+    lines += faces
+    (tmp_path / "m.obj").write_text("\n".join(lines))                      # (no newline at the end of the file)
+    xml = tmp_path / "s.xml"
+    xml.write_text('<scene><integrator type="path_mis"/><camera type="perspective"/><mesh type="obj"><string name="filename" value="m.obj"/>'
+                   '<transform name="toWorld"><scale value="1,2,0.5"/><translate value="0.25,0,0"/></transform>'
+                   '<emitter type="area"><color name="radiance" value="1 1 1"/></emitter></mesh></scene>')
+    os.environ["NORI_HIP_BVH"] = "device"                                 # no host tree: this is about the loader
+    try:
+        hs = NH.HostScene(str(xml), 16, 16, 1)
+    finally:
+        del os.environ["NORI_HIP_BVH"]
+    o = O.OracleScene(str(xml), 16, 16, 1)
+    a, b = hs.mesh(0), o.shape(0)
+    assert len(a["F"]) == 90000 + 18000
+    for k in ("V", "N", "UV", "F"):
+        assert np.array_equal(a[k], b[k]), k
+    # the positions-only form takes the direct table: the same file without vt / vn and with plain indices
+    lines2 = rows + ["f %d %d %d" % tuple(int(x) + 1 for x in rng.integers(0, nv, 3)) for _ in range(50000)]
+    (tmp_path / "m.obj").write_text("\n".join(lines2) + "\n")
+    os.environ["NORI_HIP_BVH"] = "device"
+    try:
+        hs2 = NH.HostScene(str(xml), 16, 16, 1)
+    finally:
+        del os.environ["NORI_HIP_BVH"]
+    o2 = O.OracleScene(str(xml), 16, 16, 1)
+    a, b = hs2.mesh(0), o2.shape(0)
+    assert a["N"] is None and a["UV"] is None and np.array_equal(a["V"], b["V"]) and np.array_equal(a["F"], b["F"])
+    # number parsing alone: every text, untransformed, is the float numpy (strtod then one rounding is NOT what it does: it parses to float32 correctly) gives
+    (tmp_path / "s.xml").write_text('<scene><integrator type="path_mis"/><camera type="perspective"/><mesh type="obj"><string name="filename" value="m.obj"/>'
+                                    '<emitter type="area"><color name="radiance" value="1 1 1"/></emitter></mesh></scene>')
+    (tmp_path / "m.obj").write_text("\n".join(rows + ["f %d %d %d" % (i + 1, i + 2, i + 3) for i in range(0, nv - 2, 3)]) + "\n")
+    os.environ["NORI_HIP_BVH"] = "device"
+    try:
+        hs3 = NH.HostScene(str(xml), 16, 16, 1)
+    finally:
+        del os.environ["NORI_HIP_BVH"]
+    V = hs3.mesh(0)["V"]
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6"); libc.strtof.restype = ctypes.c_float; libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    ref = np.array([[libc.strtof(t.encode(), None) for t in row] for row in want[:len(V)]], np.float32)
+    assert np.array_equal(V, ref)
+    with pytest.raises(NH.NoriHipError, match="names position"):
+        (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\n")
+        NH.HostScene(str(xml), 16, 16, 1)
+    with pytest.raises(NH.NoriHipError, match="Invalid vertex data"):
+        (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/1/1/1 2 3\n")
+        NH.HostScene(str(xml), 16, 16, 1)
+    with pytest.raises(NH.NoriHipError, match="Could not parse integer"):
+        (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 -2 3\n")
+        NH.HostScene(str(xml), 16, 16, 1)
+
+
 def test_binary_mesh_cache_round_trip(tmp_path):
     """NORI_HIP_MESH_CACHE=1: the second load reads "<obj>.noricache" instead of parsing the text and
     yields the same arrays, BVH and tables; a cache made from another toWorld or an older OBJ is ignored."""
@@ -246,6 +324,43 @@ def test_binary_mesh_cache_round_trip(tmp_path):
         n0, i0 = plain.bvh32()
         n1, i1 = hs.bvh32()
         assert np.array_equal(n0, n1) and np.array_equal(i0, i1)
+
+
+def test_host_tree_cache_round_trip(tmp_path):
+    """$NORI_HIP_BVH_CACHE: the reference-order SAH tree is written once per distinct set of primitive boxes and read back
+    afterwards; a changed mesh has another key, a damaged entry is ignored"""
+    d = str(tmp_path / "scene"); cache = tmp_path / "cache"; cache.mkdir()
+    shutil.copytree(os.path.join(SCENES, "cbox"), d)
+    xml = os.path.join(d, "cbox_path_mis.xml")
+    ref_nodes, ref_idx = NH.HostScene(xml, 32, 32, 1).bvh32()
+    ref_nodes, ref_idx = ref_nodes.copy(), ref_idx.copy()
+    os.environ["NORI_HIP_BVH_CACHE"] = str(cache)
+    try:
+        for threads in ("3", "8"):                              # the key does not depend on how many threads hash and build
+            os.environ["NORI_HIP_LOAD_THREADS"] = threads
+            hs = NH.HostScene(xml, 32, 32, 1)
+            n, i = hs.bvh32()
+            assert np.array_equal(n, ref_nodes) and np.array_equal(i, ref_idx)
+            assert len(list(cache.iterdir())) == 1
+            hs.close()
+        entry = next(cache.iterdir())
+        raw = bytearray(entry.read_bytes())
+        entry.write_bytes(bytes(raw[:len(raw) // 2]))                       # truncated entry: rebuilt, and rewritten whole
+        hs = NH.HostScene(xml, 32, 32, 1)
+        n, i = hs.bvh32()
+        assert np.array_equal(n, ref_nodes) and np.array_equal(i, ref_idx) and entry.stat().st_size == len(raw)
+        raw[-4:] = (0xFFFFFFF0).to_bytes(4, "little")                       # an index out of range: refused
+        entry.write_bytes(bytes(raw))
+        n, i = NH.HostScene(xml, 32, 32, 1).bvh32()
+        assert np.array_equal(i, ref_idx)
+        # another mesh: another entry
+        obj = os.path.join(d, "meshes", "light.obj")
+        open(obj, "a").write("\nv 0 1.5 0\nv 0.1 1.5 0\nv 0 1.5 0.1\nf 5/1 6/1 7/1\n")
+        NH.HostScene(xml, 32, 32, 1)
+        assert len(list(cache.iterdir())) == 2
+    finally:
+        del os.environ["NORI_HIP_BVH_CACHE"]
+        os.environ.pop("NORI_HIP_LOAD_THREADS", None)
 
 
 def test_png_and_pfm_writers(tmp_path):
