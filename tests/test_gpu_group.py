@@ -1,7 +1,10 @@
 """GPU: several devices behind one handle (nori_hip_group_*, the `devices` property of the path_mis plugin).  The box that runs
 these tests has one GPU, so the group has one member: the code path - contexts made by the group, per-device host threads'
 work split, RCCL communicator, in-place all-reduce on the context's stream, accumulation across calls - is the one eight GPUs take."""
+import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -69,3 +72,25 @@ def test_per_ray_li_of_the_plugin_is_the_batched_li():
     b = ctx.li_samples(np.arange(200, dtype=np.uint64), np.full(200, 0x4c69, np.uint64), rays=rays)
     assert np.array_equal(a, b) and a.sum() > 0
     hs.close()
+
+
+def test_bench_group_driver_and_strong_scaling_prediction():
+    """bench.py --driver group: one process, nori_hip_group_render over the devices present (one here, eight asked for), the same
+    JSON line as the torchrun mode with the all-reduce's device time in phases_ms_per_step; and --as-rank N, the strong-scaling
+    prediction that renders every rank's share of an N-way split on this GPU"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(*args):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for part in ("spp", "tiles"):
+        d = run("--driver", "group", "--gpus", "8", "--workload", "cbox", "--spp", "4", "--steps", "2", "--warmup", "1", "--no-cpu", "--partition", part)
+        assert d["n_gpus"] == NH.device_count() >= 1 and d["unit"] == "Msamples/s" and d["value"] > 0
+        assert d["scaling"] == ("strong" if part == "tiles" else "weak")
+        assert set(d["phases_ms_per_step"]) == {"render", "reduce", "filter"} and d["phases_ms_per_step"]["reduce"] >= 0
+        assert d["roofline"]["kernel_ms"] > 0 and "group" in d["config"]["driver"]
+    d = run("--as-rank", "4", "--workload", "cbox", "--spp", "8", "--steps", "2", "--warmup", "1")
+    assert d["n_ranks"] == 4 and d["ms_whole"] > 0
+    for part in ("tiles", "spp"):
+        p = d["partitions"][part]
+        assert len(p["ms_per_rank"]) == 4 and 0 < p["predicted_efficiency"] <= 1.5
