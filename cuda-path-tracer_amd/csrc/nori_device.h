@@ -188,6 +188,8 @@ struct DevScene {
     const uint8_t *tex_data;
     const float4 *nodes4;              // the same tree as 128-byte four-box nodes (8 x float4 per node, see Trav::box_step4), or null
     uint32_t root4;                    // child reference of the root in nodes4 numbering
+    const uint4 *nodes4q;              // device-built trees beyond the caches: the four-box nodes with quantised boxes, 64 bytes each (4 x uint4 per
+                                       // node, same numbering as nodes4; Trav::box_step4q), or null
     const uint4 *nodes8;               // device-built trees beyond the caches: the tree as 128-byte eight-box nodes with quantised boxes (Trav::box_step8;
                                        // root = node 0), or null.  When set, every traversal of a render and nori_hip_trace walk these.
     uint32_t root, n_emitters;
@@ -277,6 +279,7 @@ struct CachedNodes {
 //   ND_POP              needs an entry of the stack (pop_step)
 //   ND_DONE             traversal finished
 //   NORI_HIP_LEAF_BIT|p next leaf record to test    (prim_step)
+#define ND_Q8(W, K) ((float) (((W) >> (8 * (K))) & 0xffu))       /* byte K of word W as a float (one v_cvt_f32_ubyteK) */
 #define ND_POP  0x7ffffffeu
 #define ND_DONE 0x7fffffffu
 
@@ -446,6 +449,51 @@ template <bool ANY> struct Trav {
         box4_finish(nr, hit, ref, stk, ordered, far);
         return n_valid;
     }
+    // ---- four-box nodes with quantised boxes, 64 bytes (layout: lbvh::k_quantize4): the arithmetic of the eight-box step below on
+    // four children - slab distances t = q * (unit * rcp) + (p - o) * rcp, one byte-to-float conversion and one multiply-add per
+    // plane, near and far plane picked by the sign of the direction - and the visiting order of the four-box step above.
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step4q_fast(const uint4 *nodes4q, StackT &stk, const bool ordered, const bool sort = true, const bool far = false) {
+        const uint4 *q = nodes4q + 4 * (size_t) cur;
+        const uint4 h = q[0], a = q[1], b = q[2], r = q[3];
+        const float ax = __uint_as_float(h.w) * rcp.x, ay = __uint_as_float(b.z) * rcp.y, az = __uint_as_float(b.w) * rcp.z;
+        const float bx = (__uint_as_float(h.x) - o.x) * rcp.x, by = (__uint_as_float(h.y) - o.y) * rcp.y, bz = (__uint_as_float(h.z) - o.z) * rcp.z;
+        const bool sx = rcp.x < 0.f, sy = rcp.y < 0.f, sz = rcp.z < 0.f;
+        const uint32_t nx = sx ? a.w : a.x, fx = sx ? a.x : a.w, ny = sy ? b.x : a.y, fy = sy ? a.y : b.x, nz = sz ? b.y : a.z, fz = sz ? a.z : b.y;
+        uint32_t ref[4] = {r.x, r.y, r.z, r.w};
+        float nr[4]; bool hit[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float tnx = __builtin_fmaf(ND_Q8(nx, k), ax, bx), tfx = __builtin_fmaf(ND_Q8(fx, k), ax, bx);
+            const float tny = __builtin_fmaf(ND_Q8(ny, k), ay, by), tfy = __builtin_fmaf(ND_Q8(fy, k), ay, by);
+            const float tnz = __builtin_fmaf(ND_Q8(nz, k), az, bz), tfz = __builtin_fmaf(ND_Q8(fz, k), az, bz);
+            const float nn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, mint));
+            const float ff = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, maxt));
+            nr[k] = nn; hit[k] = (nn <= ff) & (ref[k] != NORI_HIP_NO_CHILD);
+        }
+        const uint32_t n_valid = (uint32_t) (ref[0] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[1] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[2] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[3] != NORI_HIP_NO_CHILD);
+        if (sort) box4_finish(nr, hit, ref, stk, ordered, far); else box4_finish_inorder(nr, hit, ref, stk);
+        return n_valid;
+    }
+    // any ray (a zero, denormal or NaN direction component): the boxes decoded, then the reference's test as written
+    template <typename StackT> __device__ __forceinline__ uint32_t box_step4q(const uint4 *nodes4q, StackT &stk, const bool ordered, const bool far = false) {
+        const uint4 *q = nodes4q + 4 * (size_t) cur;
+        const uint4 h = q[0], a = q[1], b = q[2], r = q[3];
+        const float u[3] = {__uint_as_float(h.w), __uint_as_float(b.z), __uint_as_float(b.w)};
+        const float p[3] = {__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z)};
+        const uint32_t lo[3] = {a.x, a.y, a.z}, hi[3] = {a.w, b.x, b.y};
+        uint32_t ref[4] = {r.x, r.y, r.z, r.w};
+        float nr[4]; bool hit[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float bmin[3], bmax[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { bmin[c] = p[c] + ND_Q8(lo[c], k) * u[c]; bmax[c] = p[c] + ND_Q8(hi[c], k) * u[c]; }
+            float nn; const bool hh = slab(bmin, bmax, o, d, rcp, mint, maxt, nn);
+            nr[k] = nn < mint ? mint : nn; hit[k] = hh & (ref[k] != NORI_HIP_NO_CHILD);
+        }
+        box4_finish(nr, hit, ref, stk, ordered, far);
+        return (uint32_t) (ref[0] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[1] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[2] != NORI_HIP_NO_CHILD) + (uint32_t) (ref[3] != NORI_HIP_NO_CHILD);
+    }
     // ---- eight-box nodes with quantised boxes (device-built trees that do not fit the caches; layout: lbvh::k_wide_emit8) -----------
     // A child's box is p + q * unit per axis with 8-bit q, low corners rounded down and high corners up, so it contains the box of
     // the binary tree: a ray reaches every record it reached before (and a few boxes more), closest hits are the same primitive
@@ -455,7 +503,6 @@ template <bool ANY> struct Trav {
     // rank is the stack position, the payload never moves), the nearest becomes `cur`, the rest go on the stack far to near.
     // Entry distances are clamped to mint from below (the pop test `entry <= maxt` is unchanged by that).
     // Returns the number of children in use (statistics).
-#define ND_Q8(W, K) ((float) (((W) >> (8 * (K))) & 0xffu))
     template <typename StackT> __device__ __forceinline__ void box8_finish(const float nr[8], const bool hit[8], const uint32_t ref[8], StackT &stk) {
         float key[8]; int rank[8];
 #pragma unroll

@@ -679,7 +679,8 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // MASKED (scenes with subsurface shapes): an extend ray whose slot holds ND_PROBE_MARK is a probe, a closest-hit query restricted
 // to the records of one shape (BVH::rayIntersect's mask, src/bvh.cpp:438).
 // PRIM2: a lane at a leaf tests both records of the leaf in one trip (Trav::prim_step2; leaves of at most two records inside one line)
-template <int KIND, bool PROF, bool SPEC, int WIDE, bool MASKED = false, bool PRIM2 = false>
+// QUANT (WIDE == 4): the four-box nodes are the 64-byte ones with quantised boxes (DevScene::nodes4q, Trav::box_step4q)
+template <int KIND, bool PROF, bool SPEC, int WIDE, bool MASKED = false, bool PRIM2 = false, bool QUANT = false>
 __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
     constexpr int DEPTH = WIDE == 8 ? TRACE_DEPTH_W8 : WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
@@ -851,6 +852,10 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
                 n_visits += (unsigned int) __popcll(m_in);
                 const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
                 const bool far = ((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 4);
+                if (QUANT) {
+                    if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4q_fast(sc.nodes4q, stk, ord, sort, far); }
+                    else if (tv.at_inner()) n_boxes_lane += tv.box_step4q(sc.nodes4q, stk, ord, far);
+                } else
                 if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort, far); }
                 else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord, far);
             } else {
@@ -894,6 +899,10 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
                     n_visits += (unsigned int) __popcll(m_in2);
                     const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
                     const bool far = ((KIND == TK_BOTH) ? any : ANY) && (sc.ordered & 4);
+                    if (QUANT) {
+                        if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4q_fast(sc.nodes4q, stk, ord, sort, far); }
+                        else if (tv.at_inner()) n_boxes_lane += tv.box_step4q(sc.nodes4q, stk, ord, far);
+                    } else
                     if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_boxes_lane += tv.box_step4_fast(sc.nodes4, stk, ord, sort, far); }
                     else if (tv.at_inner()) n_boxes_lane += tv.box_step4(sc.nodes4, stk, ord, far);
                 } else {
@@ -950,6 +959,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WA
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4_leaf2(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
     trace_pool_body<TK_BOTH, false, false, 4, false, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
 }
+// ... and with the 64-byte quantised four-box nodes
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE_WAVES))) void k_trace_pool4q_leaf2(DevScene sc, Pool pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
+    trace_pool_body<TK_BOTH, false, false, 4, false, true, true>(sc, pool, n_slots, stats, thr, box2_lanes, cnt, order);
+}
 // ... over quantised eight-box nodes (device-built trees that do not fit the caches)
 #ifndef ND_WIDE8_WAVES
 #define ND_WIDE8_WAVES 4
@@ -967,7 +980,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ND_WIDE8_W
 // owners through LDS.  Every ray is traversed by one lane with the same steps in the same order as before, so hits, any-hit answers
 // and the counts of box and record tests do not change.  Four-box nodes only.
 #define TW_RAYS 128
-template <typename StackT>
+template <bool QUANT, typename StackT>
 __device__ __forceinline__ void trace_wave4(const DevScene &sc, StackT &stk, float4 *w_o, float4 *w_d, unsigned int *w_meta, uint4 *w_hit, unsigned int *w_occ,
                                             const bool want_sh, const Ray &sh, const bool want_ex, const Ray &ex, bool &occluded, bool &found, Hit &hit,
                                             uint32_t &n_nodes, uint32_t &n_prims) {
@@ -1014,11 +1027,19 @@ __device__ __forceinline__ void trace_wave4(const DevScene &sc, StackT &stk, flo
         const unsigned long long m_in = __ballot(tv.at_inner());
         if (m_in) {
             const bool sort = __ballot(tv.at_inner() && ord) != 0ull;
+            if (QUANT) {
+                if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step4q_fast(sc.nodes4q, stk, ord, sort, far); }
+                else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step4q(sc.nodes4q, stk, ord, far); else n_nodes += tv.box_step4q_fast(sc.nodes4q, stk, ord, true, far); }
+            } else
             if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step4_fast(sc.nodes4, stk, ord, sort, far); }
             else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step4(sc.nodes4, stk, ord, far); else n_nodes += tv.box_step4_fast(sc.nodes4, stk, ord, true, far); }
         }
         const unsigned long long m_lf = __ballot(tv.at_leaf());
-        if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) { if (tv.at_leaf()) tv.prim_step(sc, n_prims, any); }
+        if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) {
+            // (QUANT implies leaves of at most two records placed inside a line: both in one trip, Trav::prim_step2)
+            if (QUANT) { if (tv.at_leaf()) (void) tv.prim_step2(sc, n_prims, any); }
+            else if (tv.at_leaf()) tv.prim_step(sc, n_prims, any);
+        }
         if (tv.at_pop()) tv.pop_step(stk);
     }
     __builtin_amdgcn_wave_barrier();
@@ -1035,7 +1056,7 @@ __device__ __forceinline__ void trace_wave4(const DevScene &sc, StackT &stk, flo
 // WAVES: waves per SIMD the kernel is built for.  With four-box nodes the fused bounce wants ≈ 170 registers: at four waves (128) it
 // spills 78 of them, at three one.  Three is 1-2 % faster on the scenes that live in the caches (cbox 25.5 -> 24.9 ms, subsurface 92.0 ->
 // 90.4), four on the 10 M-triangle scene (367 against 373 ms: there the fourth wave hides more HBM latency than the spills cost).
-template <bool EXT, int WIDE = 0, int WAVES = 4>
+template <bool EXT, int WIDE = 0, int WAVES = 4, bool QUANT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
     constexpr int FIN_DEPTH = WIDE == 4 ? 6 : LDS_DEPTH;               // stack entries per lane in LDS (the staged rays of trace_wave4 want room too)
     __shared__ uint2 lds_stack[4 * FIN_DEPTH * 64];
@@ -1117,7 +1138,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
             const bool want_sh = alive && so.has_shadow, want_ex = alive && !so.end;
             bool occluded = false, found = false; Hit nh;
             const unsigned int wv_ = threadIdx.x >> 6;
-            trace_wave4(sc, stk, tw_o + wv_ * TW_RAYS, tw_d + wv_ * TW_RAYS, tw_meta + wv_ * TW_RAYS, tw_hit + wv_ * 64, tw_occ + wv_ * 64,
+            trace_wave4<QUANT>(sc, stk, tw_o + wv_ * TW_RAYS, tw_d + wv_ * TW_RAYS, tw_meta + wv_ * TW_RAYS, tw_hit + wv_ * 64, tw_occ + wv_ * 64,
                         want_sh, so.shadow, want_ex, ps.ray, occluded, found, nh, ctr.nodes, ctr.prims);
             if (alive) {
                 if (want_sh && !occluded) ps.li = ps.li + so.contrib;
@@ -1327,6 +1348,8 @@ struct NoriHipContext {
     DevScene sc;
     uint32_t n_prims = 0, n_nodes = 0;
     float4 *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;     // the tree as 128-byte four-box nodes (null: one-leaf tree, or too deep for the stack)
+    uint4 *d_nodes4q = nullptr;                            // device-built trees beyond the caches: the four-box nodes with quantised boxes, 64 bytes each (n_nodes4 of them)
+    int quant4 = -1;                                       // NORI_HIP_QUANT: 1 / 0 = build and walk them or not; -1 = measured default (see upload_scene_impl)
     uint4 *d_nodes8 = nullptr; uint32_t n_nodes8 = 0;      // device-built trees beyond the caches: quantised eight-box nodes (null otherwise)
     bool wide = true;                 // NORI_HIP_WIDE=0: the trace stage walks the 64-byte two-box nodes
     int wide8 = 0;                    // NORI_HIP_WIDE=8: device-built trees are walked through quantised eight-box nodes (measured on the 10 M-triangle workload:
@@ -1411,6 +1434,7 @@ struct NoriHipContext {
     void free_scene() {
         hipFree(d_nodes4); d_nodes4 = nullptr; n_nodes4 = 0;
         hipFree(d_nodes8); d_nodes8 = nullptr; n_nodes8 = 0;
+        hipFree(d_nodes4q); d_nodes4q = nullptr;
         hipFree(d_env_cdf); d_env_cdf = nullptr;
         hipFree(d_nodes); hipFree(d_prims); hipFree(d_shade); hipFree(d_light); hipFree(d_shapes); hipFree(d_emitters); hipFree(d_cdf); hipFree(d_film);
         hipFree(d_textures); hipFree(d_tex_data); d_textures = nullptr; d_tex_data = nullptr; n_textures = 0; ext = false;
@@ -1468,6 +1492,7 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 64) c->lbvh_leaf = (uint32_t) v; }
     if (const char *e = getenv("NORI_HIP_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("NORI_HIP_LEAF2")) c->leaf2_step = atoi(e) != 0;
+    if (const char *e = getenv("NORI_HIP_QUANT")) c->quant4 = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("NORI_HIP_WIDE")) { const int v = atoi(e); c->wide = v != 0; c->wide8 = v == 8 ? 1 : 0; }
     if (const char *e = getenv("NORI_HIP_SORT")) c->sort_rays = atoi(e);
     if (const char *e = getenv("NORI_HIP_KEYS")) c->fused_keys = std::string(e) != "kernel";
@@ -1515,6 +1540,7 @@ static int create_impl(NoriHipContext *c, int device) {
     c->trace_lds_wide = (size_t) (c->trace_threads / 64) * (TRACE_DEPTH_W * 64 * 8 + 64 * 52);
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4_masked, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
+    HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4q_leaf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
     HIPCHK(hipFuncSetAttribute((const void *) k_trace_pool4<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->trace_lds_wide));
@@ -1688,7 +1714,8 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         if (rc) { hipFree(ctx->lbvh.nodes4); ctx->lbvh.nodes4 = nullptr; hipFree(ctx->lbvh.nodes8); ctx->lbvh.nodes8 = nullptr; hipFree(ctx->lbvh.prims_al); hipFree(ctx->lbvh.shade_al); ctx->lbvh.prims_al = ctx->lbvh.shade_al = nullptr; ctx->free_scene(); return fail(rc, lerr.empty() ? "allocation of the device-built tree failed" : lerr); }
         ctx->d_nodes4 = (float4 *) ctx->lbvh.nodes4; ctx->n_nodes4 = ctx->lbvh.n_nodes4; ctx->lbvh.nodes4 = nullptr;
         n_records = d->n_prims;
-        if (ctx->lbvh.prims_al) {
+        const bool placed = ctx->lbvh.prims_al != nullptr;
+        if (placed) {
             // the records placed leaf by leaf (no leaf straddles a line): they replace the arrays in sorted order
             hipFree(ctx->d_prims); hipFree(ctx->d_shade);
             ctx->d_prims = (NoriHipPrim *) ctx->lbvh.prims_al; ctx->d_shade = (NoriHipShadePrim *) ctx->lbvh.shade_al; ctx->lbvh.prims_al = ctx->lbvh.shade_al = nullptr;
@@ -1702,6 +1729,12 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
         {
             const bool use8 = ctx->d_nodes8 && ctx->d_nodes4 && ctx->lbvh.stack8 + 2u <= (uint32_t) ND_STACK8 && ctx->wide8 == 1;
             if (!use8) { hipFree(ctx->d_nodes8); ctx->d_nodes8 = nullptr; ctx->n_nodes8 = 0; }
+        }
+        // the 64-byte quantised four-box nodes, for the trace stage of trees beyond the caches (scenes without probe rays)
+        if (ctx->d_nodes4 && !ext && placed && (ctx->quant4 >= 0 ? ctx->quant4 != 0 : true)) {
+            void *nq = nullptr;
+            if (lbvh::quantize4(ctx->stream, ctx->d_nodes4, ctx->n_nodes4, &nq) != hipSuccess) { hipFree(nq); ctx->free_scene(); return fail(NORI_HIP_EDEVICE, "building the quantised four-box nodes failed"); }
+            ctx->d_nodes4q = (uint4 *) nq;
         }
         root = ctx->lbvh.root;
         for (int i = 0; i < 3; ++i) { root_min[i] = ctx->lbvh.root_min[i]; root_max[i] = ctx->lbvh.root_max[i]; }
@@ -1752,7 +1785,7 @@ static int upload_scene_impl(NoriHipContext *ctx, const NoriHipSceneDesc *d, con
     sc.shapes = ctx->d_shapes; sc.emitters = ctx->d_emitters; sc.cdf = ctx->d_cdf; sc.light_prims = ctx->d_light;
     sc.textures = ctx->d_textures; sc.tex_data = ctx->d_tex_data;
     // a device-built tree has no reference child order to keep: the nearer child is entered first
-    sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u; sc.nodes8 = ctx->d_nodes8;
+    sc.nodes4 = ctx->d_nodes4; sc.root4 = (root & NORI_HIP_LEAF_BIT) ? root : 0u; sc.nodes8 = ctx->d_nodes8; sc.nodes4q = ctx->d_nodes4q;
     sc.leaf2 = (device_build && n_records != d->n_prims) ? 1 : 0;            // (the placed layout: lbvh::Result::prims_al was taken over above)
     sc.root = root; sc.n_emitters = d->n_emitters; sc.n_top = n_top; sc.prim_lanes = ctx->prim_lanes; sc.cull_zero = ctx->cull_zero ? 1 : 0; {
         const size_t tree_b = (size_t) (ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
@@ -2134,6 +2167,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
                     void (*k8)(DevScene, Pool, unsigned int, DevStats *, int3, unsigned int, WfCounters *, const unsigned int *) =
                         ctx->profile ? (spec ? k_trace_pool8<true, true> : k_trace_pool8<true, false>) : (spec ? k_trace_pool8<false, true> : k_trace_pool8<false, false>);
                     hipLaunchKernelGGL(k8, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
+                } else if (wide && !spec && !ctx->profile && ctx->sc.leaf2 && ctx->leaf2_step && ctx->sc.nodes4q) {
+                    hipLaunchKernelGGL(k_trace_pool4q_leaf2, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
                 } else if (wide && !spec && !ctx->profile && ctx->sc.leaf2 && ctx->leaf2_step) {
                     hipLaunchKernelGGL(k_trace_pool4_leaf2, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
                 } else if (wide) {
@@ -2172,6 +2207,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
                 else if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide8) hipLaunchKernelGGL((k_finish<false, 8>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                else if (wide && !fin3 && ctx->sc.nodes4q && ctx->sc.leaf2) hipLaunchKernelGGL((k_finish<false, 4, 4, true>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide && fin3) hipLaunchKernelGGL((k_finish<false, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else if (wide) hipLaunchKernelGGL((k_finish<false, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
                 else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);

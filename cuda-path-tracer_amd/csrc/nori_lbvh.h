@@ -38,6 +38,9 @@ struct Result {
 int build(hipStream_t stream, uint32_t n, const NoriHipPrim *prims_in, const NoriHipShadePrim *shade_in, NoriHipPrim *prims_out,
           NoriHipShadePrim *shade_out, NoriHipNode *nodes_out, uint32_t leaf_max, float big, uint32_t max_depth, bool plain_morton, bool want8, bool align_leaves, Result &res, std::string &err);
 
+// the four-box nodes of a tree as 64-byte nodes with quantised boxes (layout: k_quantize4 in nori_lbvh.hip; Trav::box_step4q)
+hipError_t quantize4(hipStream_t stream, const void *nodes4, uint32_t n, void **out);
+
 // radix sort of n (key, value) pairs of 32 bits each on key bits [begin_bit, end_bit); `temp` of sort_pairs_temp_bytes(n) bytes
 size_t sort_pairs_temp_bytes(uint32_t n);
 hipError_t sort_pairs(hipStream_t stream, void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, int end_bit, int begin_bit = 0);

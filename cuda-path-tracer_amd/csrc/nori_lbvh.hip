@@ -340,7 +340,59 @@ __global__ __launch_bounds__(256) void k_wide_emit8(uint32_t n_level, const uint
     q[6] = make_uint4(0u, 0u, 0u, 0u); q[7] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// ---- four-box nodes with quantised boxes, 64 bytes (Trav::box_step4q in nori_device.h): the four-box node above with its children's
+// boxes stored as 8-bit offsets from the node's own low corner `p`, in units of 1/255 of the node's extent per axis (a float per
+// axis: unlike the eight-box node there is room for one, and a unit that is not rounded up to a power of two grows the boxes less).
+// Same numbering and child references as the node it is made from, so one thread converts one node.  Layout, 16 words:
+//   0-2  p (float3)     3  unit x
+//   4 low x of children 0..3, a byte each | 5 low y | 6 low z | 7 high x | 8 high y | 9 high z | 10 unit y | 11 unit z
+//   12-15 child references (an unused slot: NORI_HIP_NO_CHILD, low 255, high 0)
+// Half the bytes per visit, four 16-byte loads instead of seven, two nodes per HBM line; the boxes only ever grow (low corners
+// round down, high corners up), so a ray reaches every record it reached before.
+__global__ __launch_bounds__(256) void k_quantize4(uint32_t n, const float4 *nodes4, uint4 *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 *q = nodes4 + 8 * (size_t) i;
+    const float4 mn4[3] = {q[0], q[1], q[2]}, mx4[3] = {q[3], q[4], q[5]}, r4 = q[6];
+    const uint32_t ref[4] = {__float_as_uint(r4.x), __float_as_uint(r4.y), __float_as_uint(r4.z), __float_as_uint(r4.w)};
+    float p[3], un[3]; uint32_t wlo[3], whi[3];
+    for (int a = 0; a < 3; ++a) {
+        const float mn[4] = {mn4[a].x, mn4[a].y, mn4[a].z, mn4[a].w}, mx[4] = {mx4[a].x, mx4[a].y, mx4[a].z, mx4[a].w};
+        float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+        for (int k = 0; k < 4; ++k) if (ref[k] != NORI_HIP_NO_CHILD) { lo = fminf(lo, mn[k]); hi = fmaxf(hi, mx[k]); }
+        p[a] = lo;
+        const float ext = hi - lo;
+        // (254, not 255: room for the upward correction of a high corner; a flat node gets the smallest normal number)
+        float unit = ext / 254.0f; if (!(unit >= 1.17549435e-38f)) unit = 1.17549435e-38f;
+        un[a] = unit;
+        uint32_t ql4[4] = {255u, 255u, 255u, 255u}, qh4[4] = {0u, 0u, 0u, 0u};
+        for (int k = 0; k < 4; ++k) if (ref[k] != NORI_HIP_NO_CHILD) {
+            float ql = floorf((mn[k] - lo) / unit); ql = fminf(fmaxf(ql, 0.f), 255.f);
+            while (ql > 0.f && lo + ql * unit > mn[k]) ql -= 1.f;
+            float qh = ceilf((mx[k] - lo) / unit); qh = fminf(fmaxf(qh, 0.f), 255.f);
+            while (qh < 255.f && lo + qh * unit < mx[k]) qh += 1.f;
+            ql4[k] = (uint32_t) ql; qh4[k] = (uint32_t) qh;
+        }
+        wlo[a] = ql4[0] | (ql4[1] << 8) | (ql4[2] << 16) | (ql4[3] << 24); whi[a] = qh4[0] | (qh4[1] << 8) | (qh4[2] << 16) | (qh4[3] << 24);
+    }
+    uint4 *o = out + 4 * (size_t) i;
+    o[0] = make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), __float_as_uint(un[0]));
+    o[1] = make_uint4(wlo[0], wlo[1], wlo[2], whi[0]);
+    o[2] = make_uint4(whi[1], whi[2], __float_as_uint(un[1]), __float_as_uint(un[2]));
+    o[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
+}
+
 } // namespace
+
+// nodes4: n four-box nodes (device memory).  *out: n 64-byte quantised nodes, hipMalloc'ed here, owned by the caller.
+hipError_t quantize4(hipStream_t stream, const void *nodes4, uint32_t n, void **out) {
+    *out = nullptr;
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc(out, (size_t) n * 64);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_quantize4, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, (const float4 *) nodes4, (uint4 *) *out);
+    return hipGetLastError();
+}
 
 // The order of the key bits decides which axis the radix tree splits at each level.  A plain Morton code alternates x, y, z
 // whatever the geometry; on a scene whose primitives are long on one axis (a height field of needles: millimetres wide, a
