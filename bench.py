@@ -154,7 +154,10 @@ def group_mode(args):
     samples = w["width"] * w["height"] * spp_total * args.steps
     launches = max(1, st["extend_launches"])
     kernel_ms = st["extend_ms"] / launches
-    alg_bytes = (32.0 * st["extend_boxes"] + 40.0 * st["extend_prims"] + 60.0 * st["extend_rays"]) / launches
+    if st["extend_width"] == 4 and st["extend_node_bytes"] == 64:              # quantised four-box nodes: 64 B per visit (see main())
+        alg_bytes = (64.0 * st["extend_visits"] + 40.0 * st["extend_prims"] + 60.0 * st["extend_rays"]) / launches
+    else:
+        alg_bytes = (32.0 * st["extend_boxes"] + 40.0 * st["extend_prims"] + 60.0 * st["extend_rays"]) / launches
     kname = c0.trace_kernel_name()
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if st["extend_launches"] else 0.0
     traffic, issue = committed_traffic(args, kname, bvh) if n_dev == 1 else (None, None)
@@ -461,11 +464,13 @@ def main():
     total_samples = samples_per_step * args.steps * (1 if tiles else world)
     rays = rays_rank / args.steps                                              # this rank, per step
     # algorithmic bytes: 32 B per box tested + 40 B per primitive record tested + 44 B ray in + 16 B hit out per ray
+    survey_bytes = None
     if wavefront:
-        if st["extend_width"] == 8:
-            # quantised eight-box nodes: a visit reads one 128-byte node whatever the number of children in use (a box is 6 bytes
-            # there, not the reference's 32: counting 32 B per box tested would credit the kernel with bytes nobody needs)
-            alg_bytes = 128.0 * st["extend_visits"] / launches + 40.0 * k_prims + 60.0 * k_rays
+        if st["extend_width"] == 8 or (st["extend_width"] == 4 and st["extend_node_bytes"] == 64):
+            # quantised nodes (eight boxes in 128 B, or four in 64 B): a visit reads one node whatever the number of children in use (a box
+            # is 6 bytes there, not the reference's 32: counting 32 B per box tested would credit the kernel with bytes nobody needs)
+            alg_bytes = float(st["extend_node_bytes"]) * st["extend_visits"] / launches + 40.0 * k_prims + 60.0 * k_rays
+            survey_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays
         else:
             alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays          # per trace launch
         kname = ctx.trace_kernel_name()
@@ -498,7 +503,8 @@ def main():
         "roofline": roofline_dict(kname, achieved, kernel_ms, traffic, issue, roof_note, extra={
                      "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
                      "boxes_tested_per_ray": round(st["boxes_tested"] / max(1.0, rays_rank), 2), "prims_tested_per_ray": round(st["prims_tested"] / max(1.0, rays_rank), 2),
-                     "node_width": int(st["extend_width"]), "node_visits_per_ray": (round(st["extend_visits"] / max(1.0, st["extend_rays"]), 2) if wavefront else None)}),
+                     "node_width": int(st["extend_width"]), "node_bytes": int(st["extend_node_bytes"]) if wavefront else None,
+                     "achieved_at_32_bytes_per_box": (round(survey_bytes / (kernel_ms * 1e-3) / 1e9, 1) if survey_bytes else None), "node_visits_per_ray": (round(st["extend_visits"] / max(1.0, st["extend_rays"]), 2) if wavefront else None)}),
     }
     if secondary:
         out["secondary"] = secondary

@@ -1355,6 +1355,7 @@ struct NoriHipContext {
     int wide8 = 0;                    // NORI_HIP_WIDE=8: device-built trees are walked through quantised eight-box nodes (measured on the 10 M-triangle workload:
                                       // a third fewer node fetches, but 2.5 x the instructions per visit; slower than four-box nodes, so an option, not a default)
     uint64_t trace_width = 0;         // boxes per node in the trace stage of the last render (NoriHipStats::extend_width)
+    uint64_t trace_node_bytes = 0;    // ... and the size of that node (NoriHipStats::extend_node_bytes)
     size_t trace_lds_wide8 = 0;
     size_t trace_lds_wide = 0;
     NoriHipNode *d_nodes = nullptr; NoriHipPrim *d_prims = nullptr; NoriHipShadePrim *d_shade = nullptr, *d_light = nullptr;
@@ -2032,7 +2033,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         job.tiles = reinterpret_cast<const int4 *>(ctx->d_tiles); job.patch_first = reinterpret_cast<const unsigned int *>(ctx->d_tiles + 4 * ND_MAX_TILES);
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
-    ctx->trace_width = 0;
+    ctx->trace_width = 0; ctx->trace_node_bytes = 0;
     const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS, direct = ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS;
     // Scenes with images or subsurface shapes: the stages when the scene has subsurface shapes (their probe rays go through the trace
     // stage) and a tree with inner nodes, else the single kernel (image lookups on a few dozen primitives: measured faster).
@@ -2107,6 +2108,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const bool sort_rays = ctx->sort_rays < 0 ? big_tree : ctx->sort_rays != 0;
     const bool wide8 = wide && ctx->d_nodes8 != nullptr && !ctx->has_ss;                  // ... over quantised eight-box nodes
     ctx->trace_width = wide8 ? 8 : wide ? 4 : 2;
+    ctx->trace_node_bytes = wide8 ? 128 : wide ? 128 : 64;
     const int trace_waves = wide8 ? ND_WIDE8_WAVES : wide ? ND_WIDE_WAVES : 6;            // waves per SIMD the kernel is built for
     const size_t trace_fixed = wide8 ? ctx->trace_lds_wide8 : wide ? ctx->trace_lds_wide : ctx->trace_lds;               // stacks + staged rays (origin, direction, reciprocal direction, slot)
     int trace_bpc = ctx->trace_blocks_per_cu;
@@ -2168,6 +2170,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
                         ctx->profile ? (spec ? k_trace_pool8<true, true> : k_trace_pool8<true, false>) : (spec ? k_trace_pool8<false, true> : k_trace_pool8<false, false>);
                     hipLaunchKernelGGL(k8, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
                 } else if (wide && !spec && !ctx->profile && ctx->sc.leaf2 && ctx->leaf2_step && ctx->sc.nodes4q) {
+                    ctx->trace_node_bytes = 64;
                     hipLaunchKernelGGL(k_trace_pool4q_leaf2, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
                 } else if (wide && !spec && !ctx->profile && ctx->sc.leaf2 && ctx->leaf2_step) {
                     hipLaunchKernelGGL(k_trace_pool4_leaf2, dim3(trace_blocks), dim3(trace_threads), trace_lds, ctx->stream, ctx->sc, pools[pi], P, ctx->d_stats, thr, trace_box2, c, order);
@@ -2344,7 +2347,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     ctx->fold_ext_events();
     ctx->stats.extend_ms = ctx->ext_ms_acc; ctx->stats.extend_launches = ctx->ext_launches;
     ctx->stats.extend_rays = ds.ext_rays; ctx->stats.extend_boxes = ds.ext_nodes; ctx->stats.extend_prims = ds.ext_prims;
-    ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width; ctx->stats.shadow_rays_culled = ds.culled; ctx->stats.ss_paths_dropped = ds.dropped;
+    ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width; ctx->stats.extend_node_bytes = ctx->trace_node_bytes; ctx->stats.shadow_rays_culled = ds.culled; ctx->stats.ss_paths_dropped = ds.dropped;
     if (ctx->profile) {
         static const char *names[10] = {"trips", "box_runs", "box_lanes", "prim_runs", "prim_lanes", "pop_runs", "pop_lanes", "refill_runs", "retired", "busy_lanes"};
         for (int k = 0; k < 2; ++k) {

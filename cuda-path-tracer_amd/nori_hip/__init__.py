@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint64), ("render_ms", C.c_double),
                 ("extend_ms", C.c_double), ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("extend_boxes", C.c_uint64),
                 ("extend_prims", C.c_uint64), ("extend_visits", C.c_uint64), ("extend_width", C.c_uint64), ("shadow_rays_culled", C.c_uint64),
-                ("ss_paths_dropped", C.c_uint64)]
+                ("ss_paths_dropped", C.c_uint64), ("extend_node_bytes", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("lmin", "<f4", 3), ("lmax", "<f4", 3), ("rmin", "<f4", 3), ("rmax", "<f4", 3), ("left", "<u4"), ("right", "<u4"),
@@ -281,8 +281,10 @@ class Context:
         """the kernel bench.py's roofline is quoted on (the trace stage of the wavefront pipeline)"""
         if os.environ.get("NORI_HIP_MERGE", "1") == "0":
             return "k_trace_pool<TK_EXTEND>"
-        width = self.stats()["extend_width"]
-        return {8: "k_trace_pool8", 4: "k_trace_pool4"}.get(width, "k_trace_pool<TK_BOTH>")
+        st = self.stats()
+        if st["extend_width"] == 4 and st["extend_node_bytes"] == 64:
+            return "k_trace_pool4q"                                   # 64-byte quantised four-box nodes (k_trace_pool4q_leaf2)
+        return {8: "k_trace_pool8", 4: "k_trace_pool4"}.get(st["extend_width"], "k_trace_pool<TK_BOTH>")
 
     def clear_film(self):
         _hchk(self.L.nori_hip_clear_film(self.h))

@@ -199,6 +199,8 @@ typedef struct NoriHipStats {
     uint64_t ss_paths_dropped;     /* subsurface bounces whose 4096 probe rays all left the shape: the reference would go on probing
                                       (src/pathMisIntegrator.cpp:88-90), here the path ends and the radiance it had gathered so far IS splatted
                                       with full weight (a bias, counted here so that it is never silent; 0 on every scene the reference ships) */
+    uint64_t extend_node_bytes;    /* size of the node the trace stage of the last render fetched per visit: 64 (two boxes, or four quantised
+                                      boxes: device-built trees with placed leaves, NORI_HIP_QUANT) or 128 (four float boxes, eight quantised) */
 } NoriHipStats;
 
 typedef struct NoriHipContext NoriHipContext;

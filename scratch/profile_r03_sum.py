@@ -28,7 +28,7 @@ open(out + '/pmc_summary.txt', 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines))
 bench = json.load(open(out + '/bench.json'))
 kname = bench['roofline']['kernel']
-key = 'k_trace_pool4' if kname == 'k_trace_pool4' else 'k_trace_pool'
+key = 'k_trace_pool4' if kname.startswith('k_trace_pool4') else 'k_trace_pool'
 n = len(calls[(key, 'FETCH_SIZE')])
 if n:
     fetch, write = 2.0 * tot[(key, 'FETCH_SIZE')] * 1024.0 / n, tot[(key, 'WRITE_SIZE')] * 1024.0 / max(1, len(calls[(key, 'WRITE_SIZE')]))
