@@ -669,7 +669,10 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // WIDE: the tree is walked through its 128-byte four-box nodes (DevScene::nodes4, Trav::box_step4): every fetch uses a whole
 // HBM line and a ray's chain of dependent fetches is about half as long; up to three stack entries per visit, so the LDS part of
 // the stack is deeper (TRACE_DEPTH_W).
-#define TRACE_DEPTH_W 8
+#ifndef TRACE_DEPTH_W
+#define TRACE_DEPTH_W 9      /* 20 waves per CU x (9 x 512 B of stack + 3328 B of staged rays) = 155 KB of the 160 KB */
+#endif
+#define TRACE_DEPTH_Q (TRACE_DEPTH_W * 4 / 3)   /* ... of the kernel over quantised four-box nodes: 6-byte entries (LdsStack6T), same LDS */
 #ifndef TRACE_DEPTH_W8
 #define TRACE_DEPTH_W8 8     /* ... of the eight-box trace stage (up to seven entries per visit) */
 #endif
@@ -682,11 +685,13 @@ enum { TK_EXTEND = 0, TK_SHADOW = 1, TK_BOTH = 2 };
 // QUANT (WIDE == 4): the four-box nodes are the 64-byte ones with quantised boxes (DevScene::nodes4q, Trav::box_step4q)
 template <int KIND, bool PROF, bool SPEC, int WIDE, bool MASKED = false, bool PRIM2 = false, bool QUANT = false>
 __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &pool, unsigned int n_slots, DevStats *stats, int3 thr, unsigned int box2_lanes, WfCounters *cnt, const unsigned int *order) {
-    constexpr int DEPTH = WIDE == 8 ? TRACE_DEPTH_W8 : WIDE ? TRACE_DEPTH_W : TRACE_DEPTH;
+    constexpr int DEPTH = WIDE == 8 ? TRACE_DEPTH_W8 : WIDE ? (QUANT ? TRACE_DEPTH_Q : TRACE_DEPTH_W) : TRACE_DEPTH;
+    typedef typename std::conditional<QUANT, LdsStack6T<DEPTH>, LdsStackT<DEPTH> >::type StackLds;
+    static_assert(!QUANT || (StackLds::WAVE_BYTES == TRACE_DEPTH_W * 64 * 8), "the host sizes the LDS of the four-box trace kernels alike");
     // dynamic LDS of a workgroup of nw waves: nw stacks | nw x 64 staged ray origins | directions | reciprocal directions | slots
     extern __shared__ float4 dyn_lds[];
     const unsigned int nw = blockDim.x >> 6;
-    float4 *st_o_all = dyn_lds + nw * (DEPTH * 64 * 8 / 16);
+    float4 *st_o_all = dyn_lds + nw * (StackLds::WAVE_BYTES / 16);
     float4 *st_d_all = st_o_all + nw * 64, *st_r_all = st_d_all + nw * 64;
     unsigned int *st_slot_all = reinterpret_cast<unsigned int *>(st_r_all + nw * 64);
     float4 *const st_o = st_o_all + (threadIdx.x >> 6) * 64, *const st_d = st_d_all + (threadIdx.x >> 6) * 64, *const st_r = st_r_all + (threadIdx.x >> 6) * 64;
@@ -728,7 +733,7 @@ __device__ __forceinline__ void trace_pool_body(const DevScene &sc, const Pool &
     unsigned int l_slot = 0;                                             // the slot of this lane's ray of the batch in flight
     unsigned int s_pos = 0, s_n = 0;                                     // wave-uniform: staged rays [s_pos, s_n) wait in LDS
     uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - DEPTH];
-    LdsStackT<DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) dyn_lds + wv * (DEPTH * 64) + lane;
+    StackLds stk; stk.spill = stack_spill; stk.attach(dyn_lds, wv, lane);
     unsigned int n_boxes_lane = 0;
     unsigned int n_visits = 0;                                           // WIDE: node fetches of the wave (statistics; wave-uniform sum of ballots)                                       // WIDE: boxes of the nodes this lane visited
     // (an LDS copy of the top of the tree, CachedNodes, was measured here: no gain, and a branch per node visit)
@@ -1058,8 +1063,10 @@ __device__ __forceinline__ void trace_wave4(const DevScene &sc, StackT &stk, flo
 // 90.4), four on the 10 M-triangle scene (367 against 373 ms: there the fourth wave hides more HBM latency than the spills cost).
 template <bool EXT, int WIDE = 0, int WAVES = 4, bool QUANT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
-    constexpr int FIN_DEPTH = WIDE == 4 ? 6 : LDS_DEPTH;               // stack entries per lane in LDS (the staged rays of trace_wave4 want room too)
-    __shared__ uint2 lds_stack[4 * FIN_DEPTH * 64];
+    // stack entries per lane in LDS (the staged rays of trace_wave4 want room too: four workgroups per CU, 40 KB each at most)
+    constexpr int FIN_DEPTH = WIDE == 4 ? (QUANT ? 11 : 8) : LDS_DEPTH;
+    typedef typename std::conditional<QUANT, LdsStack6T<FIN_DEPTH>, LdsStackT<FIN_DEPTH> >::type StackLds;
+    __shared__ __align__(16) unsigned char lds_stack[4 * StackLds::WAVE_BYTES];
     // WIDE == 4: the rays of a bounce staged per wave, and their results (trace_wave4)
     __shared__ float4 tw_o[WIDE == 4 ? 4 * TW_RAYS : 1], tw_d[WIDE == 4 ? 4 * TW_RAYS : 1];
     __shared__ unsigned int tw_meta[WIDE == 4 ? 4 * TW_RAYS : 1], tw_occ[WIDE == 4 ? 4 * 64 : 1];
@@ -1070,7 +1077,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     unsigned int batch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
     unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
     uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - FIN_DEPTH];
-    LdsStackT<FIN_DEPTH> stk; stk.spill = stack_spill; stk.base = (lds_u64 *) lds_stack + (threadIdx.x >> 6) * (FIN_DEPTH * 64) + lane;
+    StackLds stk; stk.spill = stack_spill; stk.attach(lds_stack, threadIdx.x >> 6, lane);
     Counters ctr = {0, 0, 0, 0, 0, 0}; unsigned int n_invalid = 0;
     bool alive = false; unsigned int slot = 0;
     PathState ps; Pcg32 rng; Hit hit; float4 P = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -9,5 +9,5 @@ PY
 }
 run w5
 cp cuda-path-tracer_amd/libnori_hip.so /tmp/libnori_hip_w5.so
-for v in 6 4; do cp scratch/var$v/libnori_hip.so cuda-path-tracer_amd/libnori_hip.so && run w$v; done
+for v in 9 7; do cp scratch/var$v/libnori_hip.so cuda-path-tracer_amd/libnori_hip.so && run w$v; done
 cp /tmp/libnori_hip_w5.so cuda-path-tracer_amd/libnori_hip.so
