@@ -1400,7 +1400,7 @@ struct NoriHipContext {
     bool pipeline_forced = false;     // NORI_HIP_PIPELINE was given; otherwise EXT scenes take the single kernel (measured faster: the
                                       // probe rays and image lookups of their shading are per-lane work the stages cannot batch)
     int finish_waves = 0;             // NORI_HIP_FINISH_WAVES: 3 or 4 = which build of the tail kernel runs (0: three on scenes that live in the caches, four beyond)
-    unsigned int finish_below = 0;    // live paths below which k_finish takes over; 0 = a quarter of the pool (NORI_HIP_FINISH)
+    unsigned int finish_below = 0;    // live paths below which k_finish takes over; 0 = a quarter of the pool, 5/16 for trees beyond the caches (NORI_HIP_FINISH)
     int shade_waves = 4;              // k_shade variant: waves per SIMD (NORI_HIP_SHADE_WAVES = 3, 4, 5, 6 or 8)
     int shade_blocks_per_cu = 12;     // k_shade: blocks per CU (each block owns one contiguous run of the queue)
     int trace_blocks_per_cu = 0;      // persistent trace waves: workgroups per CU (all resident at once); 0 = ask the occupancy query
@@ -1424,7 +1424,7 @@ struct NoriHipContext {
                                       // caches (there the stage waits for HBM lines, and the extra boxes that speculation lets pass cost more than the waiting it saves)
     int xcd_chunks = -1;              // NORI_HIP_XCD: chunks of the sorted ray order per XCD in the trace stage's deal (0 = off, -1 = 64)
     int dyn_tries = 3;                // NORI_HIP_DYN_TRIES: queues a finishing wave tries (1..8)
-    int dyn_pct = 15;                 // NORI_HIP_DYN: percent of the trace stage's rounds of batches that are handed out dynamically at the end
+    int dyn_pct = -1;                 // NORI_HIP_DYN: percent of the trace stage's rounds of batches that are handed out dynamically at the end (-1: 15, or 25 for trees beyond the caches)
     int box2 = -1;                    // (-1 = 36) NORI_HIP_BOX2: lanes at an inner node after the pops that make the trace stage run a second box step in the trip
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
@@ -2106,7 +2106,8 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     WfCounters *c = ctx->d_cnt;
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
     const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
-    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : P / 4, P);
+    // (trees beyond the caches: the tail kernel takes over a little earlier, 5/16 of the pool - C4 286 -> 283 ms)
+    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : big_tree ? P / 16 * 5 : P / 4, P);
     // the trace stages give every wave a static share of the pool, so all their workgroups must be resident at once.
     // LDS of a workgroup: stacks + staging buffers of its waves, the rest of its share caches the top of the tree.
     const unsigned trace_threads = (unsigned) ctx->trace_threads, trace_nw = trace_threads / 64;
@@ -2124,7 +2125,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
     if (trace_share < trace_fixed) return fail(NORI_HIP_EINVAL, "trace stage: workgroup LDS share too small for its stacks");
     const unsigned int xcd_chunks = (unsigned int) (ctx->xcd_chunks >= 0 ? ctx->xcd_chunks : 64);             // sorted rays: chunks of the sorted order per XCD (0: plain round-robin deal)
-    const unsigned int trace_box2 = (unsigned int) (ctx->box2 >= 0 ? ctx->box2 : 36) | ((unsigned int) ctx->dyn_pct << 8) | ((unsigned int) ctx->dyn_tries << 16) | (xcd_chunks << 20);
+    const unsigned int trace_box2 = (unsigned int) (ctx->box2 >= 0 ? ctx->box2 : 36) | ((unsigned int) (ctx->dyn_pct >= 0 ? ctx->dyn_pct : big_tree ? 25 : 15) << 8) | ((unsigned int) ctx->dyn_tries << 16) | (xcd_chunks << 20);
     const bool spec = ctx->spec >= 0 ? ctx->spec != 0 : !big_tree;
     const size_t trace_lds = trace_fixed;
     if (ctx->profile) fprintf(stderr, "[nori_hip profile] trace stage: %u threads x %d workgroups per CU, %zu B LDS, second box step from %u lanes\n", trace_threads, trace_bpc, trace_lds, trace_box2);
