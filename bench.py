@@ -176,7 +176,7 @@ def group_mode(args):
                                   "member 0's trace stage; algorithmic bytes per SURVEY 8d, counted by the kernel itself", {"algorithmic_bytes_per_launch": int(alg_bytes)}),
         "phases_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()},
     }
-    print(json.dumps(out))
+    emit(out)
     g.close(); hs.close()
 
 
@@ -213,7 +213,7 @@ def as_rank_mode(args):
         shares = [timed(lambda: ctx.render(b, e)) for b, e in split_spp(spp, N)]
         out["partitions"]["spp"] = {"ms_per_rank": [round(x, 3) for x in shares], "ms_slowest": round(max(shares), 3),
                                     "predicted_efficiency": round(whole / (N * max(shares)), 4)}
-    print(json.dumps(out))
+    emit(out)
     hs.close()
 
 
@@ -272,7 +272,25 @@ def cpu_baseline(w, args):
             "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "scene_load_and_bvh_build_s": round(load_s, 3)}
 
 
+_JSON_FD = None
+
+
+def emit(out):
+    """the ONE JSON line of this file's contract, written to the process's original stdout"""
+    line = (json.dumps(out) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
+    # Native libraries print to stdout as they please (RCCL's version banner at communicator creation): from here on descriptor 1 is
+    # the process's stderr, and the JSON line goes to a private duplicate of the original stdout.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -516,7 +534,7 @@ def main():
         cb = cpu_baseline(w, args)
         if cb:
             out["cpu_baseline"] = cb
-    print(json.dumps(out))
+    emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -118,6 +118,65 @@ __device__ __forceinline__ float nd_atan2f(float y, float x) {
     return m == 0 ? z : m == 1 ? __uint_as_float(__float_as_uint(z) ^ 0x80000000u) : m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi;
 }
 
+// logf and expf: sysdeps/ieee754/flt-32/e_logf.c and e_expf.c (the ARM optimized-routines code): a table of 16 (1/c, log c) pairs or of
+// 32 values of 2^(i/32), a short polynomial, everything in double, one rounding to float at the end.  The multiply-adds are fused where
+// the compiler fused them in the variant glibc picks on CPUs with the instruction.  Checked against the build container's libm for EVERY
+// float: logf on all 2^31 non-negative ones, expf on all 2^32 - zero differences (scratch/glibc_logf_expf_check.c; without the fused
+// z - kd of expf, two floats differ).
+static __device__ const double ND_LOGF_TAB[16][2] = {
+    { 0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2 }, { 0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2 }, { 0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2 },
+    { 0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3 }, { 0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3 }, { 0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3 },
+    { 0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4 }, { 0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4 }, { 0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5 },
+    { 0x1p+0, 0x0p+0 }, { 0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5 }, { 0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4 },
+    { 0x1.b2036576afce6p-1, 0x1.526e57720db08p-3 }, { 0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3 }, { 0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2 },
+    { 0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2 } };
+static __device__ const unsigned long long ND_EXP2F_TAB[32] = {                      // bits of 2^(i/32) minus i << 47
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull };
+__device__ __forceinline__ float nd_logf(float x) {
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {                  // x < 2^-126, infinite or NaN
+        if (ix * 2u == 0u) return -__uint_as_float(0x7f800000u);
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return (x - x) / (x - x);
+        ix = __float_as_uint(x * 0x1p23f); ix -= 23u << 23;               // subnormal: normalised first
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int) ((tmp >> 19) & 15u), k = (int32_t) tmp >> 23;
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    const double invc = ND_LOGF_TAB[i][0], logc = ND_LOGF_TAB[i][1], z = (double) __uint_as_float(iz);
+    const double r = fma(z, invc, -1.0), y0 = fma((double) k, 0x1.62e42fefa39efp-1, logc), r2 = r * r;
+    double y = fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = fma(-0x1.00ea348b88334p-2, r2, y);
+    y = fma(y, r2, y0 + r);
+    return (float) y;
+}
+__device__ __forceinline__ float nd_expf(float x) {
+    const double xd = (double) x;
+    const uint32_t abstop = (__float_as_uint(x) >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                                               // |x| >= 88 or NaN
+        if (__float_as_uint(x) == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    const double inv = 0x1.71547652b82fep+0 * 32, shift = 0x1.8p+52;
+    const double z = inv * xd;
+    double kd = z + shift; const unsigned long long ki = (unsigned long long) __double_as_longlong(kd); kd -= shift;
+    const double r = fma(inv, xd, -kd);
+    const double s = __longlong_as_double((long long) (ND_EXP2F_TAB[ki & 31ull] + (ki << 47)));
+    const double c0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, c1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, c2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double zz = fma(c0, r, c1), r2 = r * r;
+    double y = fma(c2, r, 1.0);
+    y = fma(zz, r2, y);
+    return (float) (y * s);
+}
+
 struct F3 { float x, y, z; };
 struct F2 { float x, y; };
 
@@ -931,7 +990,7 @@ __device__ __forceinline__ F3 square_to_cosine_hemisphere(F2 s) {
     return f3(dx, dy, nd_sqrt(1.0f - dx * dx - dy * dy));
 }
 __device__ __forceinline__ F3 square_to_beckmann(F2 s, float alpha) {
-    float inner = 1.0f / (1.0f - alpha * alpha * logf(1.0f - s.x));
+    float inner = 1.0f / (1.0f - alpha * alpha * nd_logf(1.0f - s.x));
     float theta = nd_acosf(nd_sqrt(inner));
     float phi = s.y * 2.0f * ND_PI;
     float st, ct, sp, cp; nd_sincosf(theta, &st, &ct); nd_sincosf(phi, &sp, &cp);
@@ -960,7 +1019,7 @@ __device__ __forceinline__ float tan_theta(F3 v) { float temp = 1 - v.z * v.z; i
 // ---- BSDFs ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ float beckmann_D(float alpha, F3 m) {          // src/microfacet.cpp:55-61
     float temp = tan_theta(m) / alpha, ct = m.z, ct2 = ct * ct;
-    return expf(-temp * temp) / (ND_PI * alpha * alpha * ct2 * ct2);
+    return nd_expf(-temp * temp) / (ND_PI * alpha * alpha * ct2 * ct2);
 }
 __device__ __forceinline__ float smith_g1(float alpha, F3 v, F3 m) {      // src/microfacet.cpp:64-84
     float tanTheta = tan_theta(v);
@@ -1177,11 +1236,11 @@ struct ShadeOut { bool end; bool has_shadow; Ray shadow; F3 contrib; bool culled
 // ---- subsurface: where the path leaves the object (src/subsurface.cpp:106-150,199-249, src/pathMisIntegrator.cpp:86-100)
 __device__ __forceinline__ float ss_cdf(float r, float cs, float cd) {
     float rsd = -r * cs / cd;
-    return (1.0f - 0.25f * expf(rsd)) - 0.75f * expf(rsd / 3.0f);
+    return (1.0f - 0.25f * nd_expf(rsd)) - 0.75f * nd_expf(rsd / 3.0f);
 }
 __device__ __forceinline__ float ss_cdf_derivative(float r, float cs, float cd) {
     float sd = cs / cd, rsd = -r * sd;
-    return (sd * 0.25f) * (expf(rsd) + expf(rsd / 3.0f));
+    return (sd * 0.25f) * (nd_expf(rsd) + nd_expf(rsd / 3.0f));
 }
 // Subsurface::diffuseScatterPDFsample: radius by three Newton steps on the CDF, uniform angle
 __device__ __forceinline__ F2 ss_sample_disk(F2 s2, float cs, float cd) {

@@ -43,10 +43,10 @@ def main():
             ("%.3g (n=%d)" % (rest.max(), len(rest))) if len(rest) else "-", li.mean() / ref.mean()))
         hs.close()
     lines.append("")
-    lines.append("Samples off by more than 1e-3 took another branch at some comparison (Russian roulette, microfacet lobe pick, emitter CDF search, a")
-    lines.append("sample's z against 0) because a device logf / expf / log result differs from glibc's in the last place; from there on they are another,")
-    lines.append("equally distributed random path.  sin, cos, acos and atan2 are evaluated with glibc's own algorithms on the device (csrc/nori_device.h,")
-    lines.append("nd_sincosf / nd_acosf / nd_atan2f), which is why scenes whose paths only pass through those are bit-identical.")
+    lines.append("sin, cos, acos, atan2, logf and expf are evaluated on the device with glibc 2.35's own algorithms (csrc/nori_device.h: nd_sincosf, nd_acosf,")
+    lines.append("nd_atan2f, nd_logf, nd_expf; checked against the host libm in scratch/glibc_libm_check.c and, for every float there is, in")
+    lines.append("scratch/glibc_logf_expf_check.c), so a path takes the same branch at every comparison as the reference's and every sample above is the")
+    lines.append("reference's bit for bit.  (Before logf / expf were restated: 0.9985 / 0.9971 on the microfacet scenes, 0.9863 / 0.9990 on the subsurface ones.)")
     out = "\n".join(lines) + "\n"
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", "parity_fractions.txt"), "w").write(out)

@@ -24,9 +24,10 @@ SCENE_XML = {
     "cbox_checker": "cbox/cbox_checker.xml",
 }
 # per-sample Li against the reference's fixtures: bit-identical on these (see test_li_per_sample_against_reference_fixtures) ...
-EXACT_LI = {"cbox", "cbox_checker", "dragon", "cbox_path_mats", "table", "odyssey_ss"}
-# ... and at least this fraction bit-identical on the others (measured: 0.9985, 0.9971, 0.9863, 0.9990; profiles/r03_parity_fractions.txt)
-MIN_IDENTICAL = {"cbox_mirror_microfacet": 0.99, "table_microfacet": 0.99, "cbox_subsurface": 0.97, "dragon_ss": 0.99}
+# (all of them since logf / expf are glibc's too; profiles/r03_parity_fractions.txt)
+EXACT_LI = {"cbox", "cbox_checker", "dragon", "cbox_path_mats", "table", "odyssey_ss", "cbox_mirror_microfacet", "table_microfacet", "cbox_subsurface", "dragon_ss"}
+# ... and at least this fraction bit-identical on any scene added later that is not in the set above
+MIN_IDENTICAL = {}
 # scenes with images (no reference fixtures: the reference needs OpenCV to load them; the oracle's restatement is the checker)
 IMAGE_XML = {"texture_bump": "proj/textureAndBump.xml", "normal_map": "proj/normal.xml"}
 
@@ -76,12 +77,12 @@ def test_camera_rays_bit_exact_against_oracle(name, loaded):
 
 @pytest.mark.parametrize("name", list(SCENE_XML))
 def test_li_per_sample_against_reference_fixtures(name, loaded):
-    """Same pcg32 stream, same draw order, and sin / cos / acos / atan2 evaluated with glibc's own algorithms (nd_sincosf ...,
-    csrc/nori_device.h): on scenes whose paths pass through nothing else - diffuse, dielectric, mirror, the checkerboard textures,
-    path_mats, direct_mis - every sample's Li is the reference's BIT FOR BIT.  Microfacet and subsurface paths also go through
-    logf / expf / log, where the device's results differ from glibc's in the last place now and then: there nearly all samples
-    are bit-identical too, the rest agree to rounding, and a sample that takes another branch is bounded statistically.
-    Measured fractions: profiles/r03_parity_fractions.txt (thresholds below = measured minus a margin; 0.97 within 1e-3 in round 2)."""
+    """Same pcg32 stream, same draw order, and sin / cos / acos / atan2 / logf / expf evaluated with glibc's own algorithms (nd_sincosf
+    ..., csrc/nori_device.h): every sample's Li is the reference's BIT FOR BIT on every fixture scene - diffuse, dielectric, mirror,
+    microfacet, subsurface, the checkerboard textures, path_mats, direct_mis.  (The subsurface start value goes through a double log,
+    the device's own: its result is rounded to float, where a last-place difference in double shows about once in 2^29 calls.)
+    Measured fractions: profiles/r03_parity_fractions.txt (0.97 within 1e-3 in round 2).  The statistical branch below is for scenes
+    outside EXACT_LI, of which there is none at present."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     hs, ctx = loaded(name, int(g["width"]), int(g["height"]))
     sel = g["li_index"]
@@ -91,7 +92,7 @@ def test_li_per_sample_against_reference_fixtures(name, loaded):
         assert np.array_equal(li, ref), (name, (li == ref).all(1).mean())
         return
     err = np.abs(li - ref).max(1) / np.maximum(np.abs(ref).max(1), 1e-3)
-    assert (li == ref).all(1).mean() > MIN_IDENTICAL[name], (name, (li == ref).all(1).mean())
+    assert (li == ref).all(1).mean() > MIN_IDENTICAL.get(name, 0.97), (name, (li == ref).all(1).mean())
     assert (err < 1e-3).mean() > 0.995, (err < 1e-3).mean()
     assert np.abs(li.mean(0) - ref.mean(0)).max() < 0.02 * ref.mean()
     # The samples that do not match took another branch somewhere (a device-libm ulp at a roulette, lobe or emitter-pick
