@@ -346,7 +346,8 @@ def main():
     load_s = time.time() - t0
     info = hs.info()
     T = hs.tables()
-    info_ext = len(T["textures"]) > 0 or bool((T["shapes"]["bsdf"] == 4).any())      # images or subsurface shapes: the EXT kernels run
+    info_ss = bool((T["shapes"]["bsdf"] == 4).any())
+    info_ext = len(T["textures"]) > 0 or info_ss                                      # images or subsurface shapes: the EXT kernels run
     ctx = hs.preprocess(device=local)
     bi = ctx.build_info()
     film = film_tensor(ctx, torch) if world > 1 else None
@@ -494,7 +495,7 @@ def main():
         kname = ctx.trace_kernel_name()
     else:
         alg_bytes = (32.0 * st["boxes_tested"] + 40.0 * st["prims_tested"]) / args.steps + 60.0 * rays + 32.0 * samples_per_step
-        kname = "k_render_ext" if info_ext else "k_render_w%s" % os.environ.get("NORI_HIP_MEGA_WAVES", "4")
+        kname = ("k_render_ext" if info_ss else "k_render_img") if info_ext else "k_render_w%s" % os.environ.get("NORI_HIP_MEGA_WAVES", "4")
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch of the same kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, scratch/pmc.sh; the doubling
     # holds for scattered reads too: scratch/fetchprobe.hip, profiles/r02_fetchprobe.txt), which cannot run inside this
@@ -506,6 +507,9 @@ def main():
                      "under divergence (valu_issue_busy, same passes), see DESIGN.md 5")
     else:
         roof_note = "algorithmic bytes per SURVEY 8d, counted by the kernel itself; traffic = HBM bytes per launch from the committed PMC passes (null: not measured for this workload, tree and kernel)"
+        if survey_bytes:
+            roof_note += ("; this kernel reads quantised nodes, so a node visit is counted at the node's %d bytes and not at SURVEY 8d's 32 B per box tested "
+                          "(that count, comparable with earlier rounds, is achieved_at_32_bytes_per_box)" % int(st["extend_node_bytes"]))
     out = {
         "metric": "Msamples/s (path_mis, whole node)", "value": round(total_samples / dt / 1e6, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -1374,13 +1374,15 @@ __device__ __forceinline__ void shade_finish(const DevScene &sc, PathState &ps, 
 // bouncing with zero throughput, which adds exact zeros).
 // EXT: scenes with images (albedo textures, bump / normal maps) or subsurface shapes; the probe rays of the latter
 // are traced here, by the shading lane (`ctr`, if given, counts them as closest-hit rays).
-template <bool EXT = false>
+// SS (EXT only): the scene may hold subsurface shapes.  False for the single kernel of scenes that only have images: the probe
+// loop and sampleDx's double arithmetic then do not weigh on the register allocation of a kernel that never runs them.
+template <bool EXT = false, bool SS = EXT>
 __device__ __forceinline__ void shade_hit(const DevScene &sc, PathState &ps, Pcg32 &rng, const Hit &hit, ShadeOut &out, Counters *ctr = nullptr) {
     ShadeCtx cx; shade_ctx<EXT>(sc, ps.ray, hit, cx);
     if (!shade_begin(sc, ps, rng, cx, out)) return;
     // its_out: where the path continues from.  The hit itself, except for subsurface shapes (:86-100)
     F3 op = cx.sf.p; Frame osh = cx.sf.sh;
-    if (EXT && sc.shapes[cx.sf.shape].bsdf == NORI_HIP_BSDF_SUBSURFACE) {
+    if (EXT && SS && sc.shapes[cx.sf.shape].bsdf == NORI_HIP_BSDF_SUBSURFACE) {
         bool found = false;
         for (int tries = 0; tries < ND_PROBE_TRIES && !found; ++tries) {
             Ray probe; ss_probe_ray(sc, cx, rng, probe);
@@ -1415,13 +1417,13 @@ __device__ __forceinline__ void shade_resume(const DevScene &sc, PathState &ps, 
 }
 
 // One iteration of the reference's bounce loop, run to completion by one lane.  Returns false when the path ended.
-template <bool EXT = false, typename StackT, typename NodesT>
+template <bool EXT = false, bool SS = EXT, typename StackT, typename NodesT>
 __device__ __forceinline__ bool path_bounce(const DevScene &sc, const NodesT &nodes, PathState &ps, Pcg32 &rng, StackT &stk, Counters &ctr) {
     Hit hit;
     ctr.closest++;
     if (!trace<false>(sc, nodes, ps.ray, hit, stk, ctr.nodes, ctr.prims)) { ps.li = ps.li + env_miss<EXT>(sc, ps.ray.d, ps.t, ps.last_bsdf_pdf, ps.last_delta); return false; }
     ShadeOut so;
-    shade_hit<EXT>(sc, ps, rng, hit, so, &ctr);
+    shade_hit<EXT, SS>(sc, ps, rng, hit, so, &ctr);
     if (so.culled) ctr.culled++;
     if (so.has_shadow) {
         Hit sh_hit;

@@ -229,7 +229,7 @@ __device__ __forceinline__ bool film_put(const DevScene &sc, float4 *film, F2 po
 // fetch per trip), so it is built for several register budgets (waves per SIMD) and the host picks one.
 #define MEGA_THREADS 256
 #define MEGA_DEPTH 8
-template <bool EXT, int KIND = NORI_HIP_INTEGRATOR_PATH_MIS>
+template <bool EXT, int KIND = NORI_HIP_INTEGRATOR_PATH_MIS, bool SS = EXT>
 __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob &job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     extern __shared__ float4 dyn_lds[];
     uint2 stack_spill[ND_STACK - MEGA_DEPTH];
@@ -276,7 +276,7 @@ __device__ __forceinline__ void render_body(const DevScene &sc, const RenderJob 
         if (__ballot(alive) == 0ull) { if (exhausted && cursor >= end) break; else continue; }
         if (alive) {
             const bool go_on = KIND == NORI_HIP_INTEGRATOR_PATH_MATS ? path_bounce_mats<EXT>(sc, nodes, ps, rng, stk, ctr)
-                             : KIND == NORI_HIP_INTEGRATOR_DIRECT_MIS ? path_direct_mis<EXT>(sc, nodes, ps, rng, stk, ctr) : path_bounce<EXT>(sc, nodes, ps, rng, stk, ctr);
+                             : KIND == NORI_HIP_INTEGRATOR_DIRECT_MIS ? path_direct_mis<EXT>(sc, nodes, ps, rng, stk, ctr) : path_bounce<EXT, SS>(sc, nodes, ps, rng, stk, ctr);
             if (!go_on) {
                 if (!film_put(sc, film, pixel_sample, px, py, ps.li)) n_invalid++;
                 alive = false;
@@ -309,6 +309,10 @@ ND_RENDER_KERNEL(8)
 // scenes with images or subsurface shapes (DevScene::textures / NORI_HIP_BSDF_SUBSURFACE): one register budget
 __global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_ext(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     render_body<true>(sc, job, film, work_counter, stats, n_cached); }
+// ... scenes with images but no subsurface shape (textureAndBump: 2 394 ms per step through k_render_ext once sampleDx's expf went
+// through double arithmetic - 65 spilled vector registers instead of 55 in a kernel that never runs that code - and 2 192 through this one)
+__global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_img(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
+    render_body<true, NORI_HIP_INTEGRATOR_PATH_MIS, false>(sc, job, film, work_counter, stats, n_cached); }
 // NORI_HIP_INTEGRATOR_PATH_MATS (src/pathMatsIntegrator.cpp): every scene kind through one variant
 __global__ __launch_bounds__(MEGA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_mats(DevScene sc, RenderJob job, float4 *film, unsigned long long *work_counter, DevStats *stats, unsigned int n_cached) {
     render_body<true, NORI_HIP_INTEGRATOR_PATH_MATS>(sc, job, film, work_counter, stats, n_cached); }
@@ -2057,7 +2061,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         const unsigned int n_cached = share > stack_bytes ? std::min<unsigned int>(ctx->sc.n_top, (unsigned int) ((share - stack_bytes) / 64)) : 0u;
         const size_t lds = stack_bytes + (size_t) n_cached * 64;
         void (*kern)(DevScene, RenderJob, float4 *, unsigned long long *, DevStats *, unsigned int) =
-            direct ? k_render_direct : mats ? k_render_mats : ctx->ext ? k_render_ext : MW == 3 ? k_render_w3 : MW == 4 ? k_render_w4 : MW == 5 ? k_render_w5 : MW == 6 ? k_render_w6 : k_render_w8;
+            direct ? k_render_direct : mats ? k_render_mats : (ctx->ext && !ctx->has_ss) ? k_render_img : ctx->ext ? k_render_ext : MW == 3 ? k_render_w3 : MW == 4 ? k_render_w4 : MW == 5 ? k_render_w5 : MW == 6 ? k_render_w6 : k_render_w8;
         HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(MEGA_THREADS), lds, ctx->stream, ctx->sc, job, ctx->d_film, ctx->d_counter, ctx->d_stats, n_cached);
