@@ -766,6 +766,31 @@ __device__ __forceinline__ bool trace4(const DevScene &sc, const Ray &ray_in, Hi
     return tv.found;
 }
 
+// the same loop over the 64-byte quantised four-box nodes (sc.nodes4q must not be null), as the trace stage of big device-built trees
+// walks them; two records of a leaf per trip where the leaves were placed for it
+template <bool ANY, typename StackT>
+__device__ __forceinline__ bool trace4q(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
+    Trav<ANY> tv;
+    const bool ordered = (ANY && (sc.ordered & 2)) || (sc.ordered & 1);
+    const bool far = ANY && (sc.ordered & 4);
+    if (tv.begin(sc, ray_in, n_nodes)) tv.cur = sc.root4;
+    for (;;) {
+        const unsigned long long m_in = __ballot(tv.at_inner());
+        if (m_in) {
+            if (__ballot(tv.at_inner() && tv.special) == 0ull) { if (tv.at_inner()) n_nodes += tv.box_step4q_fast(sc.nodes4q, stk, ordered, true, far); }
+            else if (tv.at_inner()) { if (tv.special) n_nodes += tv.box_step4q(sc.nodes4q, stk, ordered, far); else n_nodes += tv.box_step4q_fast(sc.nodes4q, stk, ordered, true, far); }
+        }
+        const unsigned long long m_lf = __ballot(tv.at_leaf());
+        if (m_lf && (__popcll(m_lf) >= sc.prim_lanes || __ballot(tv.at_inner()) == 0ull)) {
+            if (tv.at_leaf()) { if (sc.leaf2) (void) tv.prim_step2(sc, n_prims, ANY); else tv.prim_step(sc, n_prims); }
+        }
+        if (tv.at_pop()) tv.pop_step(stk);
+        if (__ballot(!tv.done()) == 0ull) break;
+    }
+    hit = tv.hit;
+    return tv.found;
+}
+
 // the same loop over the quantised eight-box nodes (sc.nodes8 must not be null; the stack must hold ND_STACK8 entries)
 template <bool ANY, typename StackT>
 __device__ __forceinline__ bool trace8(const DevScene &sc, const Ray &ray_in, Hit &hit, StackT &stk, uint32_t &n_nodes, uint32_t &n_prims) {
@@ -793,6 +818,13 @@ template <int SIZE> struct ScratchStackT {
     __device__ __forceinline__ uint2 pop(int i) const { return e[i]; }
 };
 typedef ScratchStackT<ND_STACK> ScratchStack;
+// ... whose entries lose the low 16 bits of the entry distance, as every LDS level of LdsStack6T does (k_trace over quantised nodes:
+// nori_hip_trace then answers with the traversal the trace stage runs, and the parity tests compare exactly that with the oracle)
+template <int SIZE> struct ScratchStackCutT {
+    uint2 e[SIZE];
+    __device__ __forceinline__ void push(int i, uint2 v) { e[i] = make_uint2(v.x, ((v.y << 1) >> 16) << 15); }
+    __device__ __forceinline__ uint2 pop(int i) const { return e[i]; }
+};
 
 // Per-lane traversal stack with its first LDS_DEPTH entries in LDS ([entry][lane] layout: the 64 lanes of a wave
 // touch 64 consecutive 8-byte words, conflict-free for ds_read/write_b64) and the rare deeper entries in scratch.

@@ -55,20 +55,7 @@ struct alignas(256) DevStats { unsigned long long samples, closest, shadow, inva
 __device__ __forceinline__ DevStats *my_stats(DevStats *stats) { return stats + (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & (ND_STRIPES - 1)); }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *rays, size_t n, int any_hit, NoriHipHit *hits, float *full) {
-    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
-    float4 a = rp[0], b = rp[1];
-    Ray ray; ray.o = f3(a.x, a.y, a.z); ray.mint = a.w; ray.d = f3(b.x, b.y, b.z); ray.maxt = b.w;
-    ScratchStackT<ND_STACK8> stk; Hit hit; uint32_t nn = 0, np = 0;
-    NoriHipHit out; out.prim = NORI_HIP_MISS; out.t = 0.f; out.u = 0.f; out.v = 0.f;
-    if (any_hit) {
-        if (sc.nodes8 ? trace8<true>(sc, ray, hit, stk, nn, np) : trace<true>(sc, ray, hit, stk, nn, np)) out.prim = 1u;
-        hits[i] = out;
-        return;
-    }
-    bool found = sc.nodes8 ? trace8<false>(sc, ray, hit, stk, nn, np) : trace<false>(sc, ray, hit, stk, nn, np);
+__device__ __forceinline__ void k_trace_result(const DevScene &sc, const Ray &ray, const Hit &hit, bool found, NoriHipHit &out, float *full, size_t i) {
     if (found) {
         Surface sf; surface_from_hit<true>(sc, ray, hit, sf, true);
         out.prim = sf.prim; out.t = hit.t; out.u = sf.uv.x; out.v = sf.uv.y;
@@ -79,6 +66,31 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *ra
             f[11] = (float) sf.shape; f[12] = f[13] = f[14] = f[15] = 0.f;
         }
     } else if (full) { float *f = full + 16 * i; for (int k = 0; k < 16; ++k) f[k] = 0.f; }
+}
+__global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *rays, size_t n, int any_hit, NoriHipHit *hits, float *full) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+    float4 a = rp[0], b = rp[1];
+    Ray ray; ray.o = f3(a.x, a.y, a.z); ray.mint = a.w; ray.d = f3(b.x, b.y, b.z); ray.maxt = b.w;
+    ScratchStackT<ND_STACK8> stk; Hit hit; uint32_t nn = 0, np = 0;
+    NoriHipHit out; out.prim = NORI_HIP_MISS; out.t = 0.f; out.u = 0.f; out.v = 0.f;
+    // (a scene whose trace stage walks quantised four-box nodes is answered by that traversal here too: same node step, same two-record
+    // leaf step, stack entries cut like the trace stage's)
+    if (sc.nodes4q && !sc.nodes8) {
+        ScratchStackCutT<ND_STACK> sq;
+        if (any_hit) { if (trace4q<true>(sc, ray, hit, sq, nn, np)) out.prim = 1u; hits[i] = out; return; }
+        const bool fq = trace4q<false>(sc, ray, hit, sq, nn, np);
+        k_trace_result(sc, ray, hit, fq, out, full, i); hits[i] = out;
+        return;
+    }
+    if (any_hit) {
+        if (sc.nodes8 ? trace8<true>(sc, ray, hit, stk, nn, np) : trace<true>(sc, ray, hit, stk, nn, np)) out.prim = 1u;
+        hits[i] = out;
+        return;
+    }
+    bool found = sc.nodes8 ? trace8<false>(sc, ray, hit, stk, nn, np) : trace<false>(sc, ray, hit, stk, nn, np);
+    k_trace_result(sc, ray, hit, found, out, full, i);
     hits[i] = out;
 }
 

@@ -243,7 +243,9 @@ int nori_hip_set_film_filter(NoriHipContext *ctx, const float *table33, float ra
 /* Closest-hit (any_hit = 0) or any-hit (any_hit != 0: hits[i].prim is 1 when occluded, NORI_HIP_MISS otherwise)
  * queries for n host rays.  Replaces Scene::rayIntersect -> BVH::rayIntersect (src/bvh.cpp:404-463) including
  * Shape::setHitInformation's uv (src/mesh.cpp:137-141).  `full`, if not NULL, receives 16 floats per ray:
- * p.xyz, uv.xy, shading normal xyz, geometric normal xyz, shape index, 4 x 0 (Intersection, include/nori/shape.h:38-67). */
+ * p.xyz, uv.xy, shading normal xyz, geometric normal xyz, shape index, 4 x 0 (Intersection, include/nori/shape.h:38-67).
+ * The rays walk the node layout the render's trace stage walks for this scene where that layout changes which boxes a ray enters
+ * (quantised four- or eight-box nodes of device-built trees), so that hit parity is tested on the traversal that renders. */
 int nori_hip_trace(NoriHipContext *ctx, const NoriHipRay *rays, size_t n, int any_hit, NoriHipHit *hits, float *full);
 
 /* Same query on rays already resident in device memory (device pointers); asynchronous on the context's stream. */

@@ -72,12 +72,17 @@ def test_c4_reduced_hits_and_li_against_oracle_with_the_reference_order_tree(c4_
 
 
 @pytest.mark.parametrize("width,extra", [("4", {}), ("8", {}),
-                                         ("4", {"NORI_HIP_LBVH_ALIGN": "1", "NORI_HIP_LBVH_LEAF": "2", "NORI_HIP_ANYORDER": "far"})],
-                         ids=["four-box", "eight-box", "full-size-defaults"])
+                                         ("4", {"NORI_HIP_LBVH_ALIGN": "1", "NORI_HIP_LBVH_LEAF": "2", "NORI_HIP_ANYORDER": "far", "NORI_HIP_SPEC": "0", "NORI_HIP_FINISH_WAVES": "4"}),
+                                         ("4", {"NORI_HIP_LBVH_ALIGN": "1", "NORI_HIP_LBVH_LEAF": "2", "NORI_HIP_ANYORDER": "far", "NORI_HIP_SPEC": "0", "NORI_HIP_FINISH_WAVES": "4",
+                                                "NORI_HIP_QUANT": "0"})],
+                         ids=["four-box", "eight-box", "full-size-defaults", "full-size-defaults-float-nodes"])
 def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small, width, extra):
     """width 8: the device-built tree as quantised eight-box nodes (NORI_HIP_WIDE=8; boxes only ever enlarged).
     full-size-defaults: what a tree of a million records or more gets by itself - leaves of two records placed so that none
-    straddles a 128-byte line (two of eight record positions stay empty), any-hit rays entering the farthest child first."""
+    straddles a 128-byte line (two of eight record positions stay empty), any-hit rays entering the farthest child first, no
+    speculative traversal, the tail kernel built for four waves per SIMD, and the
+    trace stage and the tail kernel over 64-byte quantised four-box nodes with six-byte stack entries (k_trace_pool4q_leaf2,
+    k_finish<false, 4, 4, true>); -float-nodes: the same tree through the 128-byte nodes (k_trace_pool4_leaf2)."""
     W = H = 96
     hs = NH.HostScene(c4_small, W, H, 4)
     ctx = hs.preprocess()
@@ -105,6 +110,9 @@ def test_c4_reduced_device_built_tree_agrees_with_the_host_tree(c4_small, width,
     ctx.clear_film(); ctx.render(0, 4); cd.clear_film(); cd.render(0, 4)
     fa, fb = ctx.read_film(), cd.read_film()
     assert cd.stats()["extend_width"] == int(width)
+    if "NORI_HIP_LBVH_ALIGN" in extra:
+        assert cd.stats()["extend_node_bytes"] == (128 if extra.get("NORI_HIP_QUANT") == "0" else 64)
+        assert cd.trace_kernel_name() == ("k_trace_pool4" if extra.get("NORI_HIP_QUANT") == "0" else "k_trace_pool4q")
     assert np.array_equal(fa[:, :, 3], fb[:, :, 3])
     assert abs(fa[:, :, :3].sum() - fb[:, :, :3].sum()) < 2e-3 * fa[:, :, :3].sum()
     hs.close(); hd.close()
@@ -148,7 +156,39 @@ def test_c4_full_size_properties_on_the_device_built_tree():
     ctx.clear_film(); ctx.render_tiles(0, 2, [(0, y, W, min(y + 32, H)) for y in range(0, H, 32)])
     ft = ctx.read_film()
     assert np.array_equal(ft[..., 3], f2[..., 3]) and np.allclose(ft, f2, rtol=1e-4, atol=1e-5)
-    hs.close()
+    # what ran is the kernel the benchmark is quoted on: 64-byte quantised four-box nodes, six-byte stack entries ...
+    assert s4["extend_width"] == 4 and s4["extend_node_bytes"] == 64 and ctx.trace_kernel_name() == "k_trace_pool4q"
+    # ... and the same tree through the 128-byte float nodes gives the same film: quantised boxes only ever grow, the stack's entry
+    # distances are only ever rounded down, so the same records are reached (pixels may differ where two triangles tie in t and the
+    # children's order by entry distance differs)
+    os.environ.update({"NORI_HIP_BVH": "device", "NORI_HIP_QUANT": "0"})
+    try:
+        hf = synthetic.make_c4(2236, W, H, 2)            # (a context of its own: the knobs are read by nori_hip_create)
+        cf = hf.preprocess()
+    finally:
+        del os.environ["NORI_HIP_BVH"], os.environ["NORI_HIP_QUANT"]
+    cf.clear_film(); cf.reset_stats(); cf.render(0, 2)
+    ff, sf = cf.read_film(), cf.stats()
+    assert sf["extend_node_bytes"] == 128
+    assert np.array_equal(ff[..., 3], f2[..., 3])
+    same = (ff == f2).all(-1).mean()
+    print("full-size C4, quantised against float nodes: %.5f of the pixels bit-identical" % same)
+    assert same > 0.995, same
+    # ray by ray (nori_hip_trace walks the quantised nodes with cut stack entries in ctx, the two-box float nodes in cf): the same
+    # distance for every ray, bit for bit, and another primitive only where two tie at that distance
+    bounce = rays.copy(); bounce[:, 0:3] = full[:, 0:3]; bounce[:, 3] = 1e-4
+    d = rng.normal(size=(len(rays), 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[(d * full[:, 8:11]).sum(1) < 0] *= -1; bounce[:, 4:7] = d; bounce[:, 7] = np.inf
+    for r in (rays, bounce):
+        a, b = ctx.trace(r), cf.trace(r)
+        assert np.array_equal(a["t"], b["t"])
+        ties = (a["prim"] != b["prim"]).mean()
+        print("full-size C4, quantised against float nodes, %d rays: %.6f name another primitive at the same t" % (len(r), ties))
+        assert ties < 0.005, ties
+    sh2 = bounce.copy(); sh2[:, 7] = 0.7
+    assert np.array_equal(ctx.trace(sh2, any_hit=True)["prim"], cf.trace(sh2, any_hit=True)["prim"])
+    assert abs(ff[..., :3].sum() - f2[..., :3].sum()) < 1e-4 * f2[..., :3].sum()
+    hs.close(); hf.close()
 
 
 @pytest.mark.skipif(os.environ.get("NORI_HIP_TEST_FULL") == "0", reason="NORI_HIP_TEST_FULL=0: skip the minute of host work (450 MB of OBJ text, a one-thread SAH build)")
