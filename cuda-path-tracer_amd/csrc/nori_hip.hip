@@ -641,14 +641,15 @@ ND_SHADE_KERNEL(4)
 ND_SHADE_KERNEL(5)
 ND_SHADE_KERNEL(6)
 ND_SHADE_KERNEL(8)
-__global__ __launch_bounds__(256) void k_shade_ext(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
+// (three waves per SIMD: left to itself the compiler takes 191 registers for two since sampleDx's expf runs in double arithmetic)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_shade_ext(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
                                                    WfCounters *cnt, unsigned long long *work_counter, DevStats *stats, unsigned int *keys) {
     shade_body<true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
 // ... writing the ray sort's keys too (the default variants only)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_shade_w4_keys(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live, WfCounters *cnt,
                      unsigned long long *work_counter, DevStats *stats, unsigned int *keys) { shade_body<false, true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
-__global__ __launch_bounds__(256) void k_shade_ext_keys(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_shade_ext_keys(DevScene sc, Pool pool, unsigned int n_slots, RenderJob job, float4 *film, unsigned int *q_live,
                                                         WfCounters *cnt, unsigned long long *work_counter, DevStats *stats, unsigned int *keys) {
     shade_body<true, true>(sc, pool, n_slots, job, film, q_live, cnt, work_counter, stats, keys); }
 
