@@ -420,8 +420,10 @@ __device__ __forceinline__ unsigned int spread10(unsigned int x) {
 #define ND_NO_KEY 0x3fffffffu            /* a slot without a ray: sorts last */
 __device__ __forceinline__ unsigned int cell_key(const DevScene &sc, float px, float py, float pz) {
     const float ex = sc.root_max[0] - sc.root_min[0], ey = sc.root_max[1] - sc.root_min[1], ez = sc.root_max[2] - sc.root_min[2];
-    const float qx = ex > 0.f ? (px - sc.root_min[0]) / ex : 0.f, qy = ey > 0.f ? (py - sc.root_min[1]) / ey : 0.f, qz = ez > 0.f ? (pz - sc.root_min[2]) / ez : 0.f;
-    const unsigned int ix = (unsigned int) fminf(fmaxf(qx * 1024.f, 0.f), 1023.f), iy = (unsigned int) fminf(fmaxf(qy * 1024.f, 0.f), 1023.f), iz = (unsigned int) fminf(fmaxf(qz * 1024.f, 0.f), 1023.f);
+    // (cells per unit length: loop-invariant, so the three divisions leave the shade stage's loop; the key only orders the work)
+    const float sx = ex > 0.f ? 1024.f / ex : 0.f, sy = ey > 0.f ? 1024.f / ey : 0.f, sz = ez > 0.f ? 1024.f / ez : 0.f;
+    const float qx = (px - sc.root_min[0]) * sx, qy = (py - sc.root_min[1]) * sy, qz = (pz - sc.root_min[2]) * sz;
+    const unsigned int ix = (unsigned int) fminf(fmaxf(qx, 0.f), 1023.f), iy = (unsigned int) fminf(fmaxf(qy, 0.f), 1023.f), iz = (unsigned int) fminf(fmaxf(qz, 0.f), 1023.f);
     const unsigned int key = (spread10(ix) << 2) | (spread10(iy) << 1) | spread10(iz);
     return key == ND_NO_KEY ? ND_NO_KEY - 1u : key;
 }

@@ -9,9 +9,6 @@ import json; d=json.load(open("gpurun_out/r3_sw_$tag.json")); r=d["roofline"]; p
 PY
 }
 run base A=1
-run spec1 NORI_HIP_SPEC=1
-run spec1_b0 NORI_HIP_SPEC=1 NORI_HIP_BOX2=0
-run r8 NORI_HIP_THR=1,1,8
 run base2 A=1
 if [ -f scratch/var4/libnori_hip.so ]; then
   cp cuda-path-tracer_amd/libnori_hip.so /tmp/libnori_hip_w5.so
