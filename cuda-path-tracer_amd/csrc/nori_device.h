@@ -849,6 +849,9 @@ typedef LdsStackT<LDS_DEPTH> LdsStack;
 // (the 10 M-triangle scene: 8 levels 319 ms a step, 9 levels 305).  Entry distances are never negative (they are clamped to mint), so the
 // distance read back is at most the one stored: the test at the pop, entry <= maxt, lets a few more entries through and never drops one -
 // such an entry's boxes or records are then tested against the exact maxt, so no result changes.  Deeper levels keep all 32 bits.
+// Precondition: mint >= 0 (the sign bit is not stored).  Every ray of a render over quantised nodes satisfies it - camera rays start at the
+// near clip, bounce and shadow rays at 1e-3; the probe rays of subsurface shapes (mint = -1e-3) belong to scenes that keep the float nodes
+// and 8-byte entries.
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 typedef __attribute__((address_space(3))) unsigned short lds_u16;
 template <int DEPTH> struct LdsStack6T {

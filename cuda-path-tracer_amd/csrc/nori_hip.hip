@@ -78,9 +78,12 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, const NoriHipRay *ra
     // (a scene whose trace stage walks quantised four-box nodes is answered by that traversal here too: same node step, same two-record
     // leaf step, stack entries cut like the trace stage's)
     if (sc.nodes4q && !sc.nodes8) {
-        ScratchStackCutT<ND_STACK> sq;
-        if (any_hit) { if (trace4q<true>(sc, ray, hit, sq, nn, np)) out.prim = 1u; hits[i] = out; return; }
-        const bool fq = trace4q<false>(sc, ray, hit, sq, nn, np);
+        // (entry distances are at least mint: the cut entries, which have no sign bit, are for rays with mint >= 0 - every ray a render
+        // traces over these nodes; a caller's ray with a negative mint keeps full entries)
+        bool fq;
+        if (ray.mint >= 0.f) { ScratchStackCutT<ND_STACK> sq; fq = any_hit ? trace4q<true>(sc, ray, hit, sq, nn, np) : trace4q<false>(sc, ray, hit, sq, nn, np); }
+        else fq = any_hit ? trace4q<true>(sc, ray, hit, stk, nn, np) : trace4q<false>(sc, ray, hit, stk, nn, np);
+        if (any_hit) { if (fq) out.prim = 1u; hits[i] = out; return; }
         k_trace_result(sc, ray, hit, fq, out, full, i); hits[i] = out;
         return;
     }

@@ -187,6 +187,12 @@ def test_c4_full_size_properties_on_the_device_built_tree():
         assert ties < 0.005, ties
     sh2 = bounce.copy(); sh2[:, 7] = 0.7
     assert np.array_equal(ctx.trace(sh2, any_hit=True)["prim"], cf.trace(sh2, any_hit=True)["prim"])
+    # rays that start behind their origin (mint < 0, as the probe rays of subsurface shapes do): the cut stack entries carry no sign,
+    # so such rays keep full entries - same answers again
+    neg = bounce.copy(); neg[:, 3] = -0.05; neg[:, 7] = 0.04
+    a, b = ctx.trace(neg), cf.trace(neg)
+    assert np.array_equal(a["t"], b["t"]) and (a["prim"] != b["prim"]).mean() < 0.005 and (a["t"][a["prim"] != NH.MISS] < 0.04 + 1e-6).all()
+    assert ((a["prim"] != NH.MISS) & (a["t"] < 0)).any()          # (some of them do hit behind the origin)
     assert abs(ff[..., :3].sum() - f2[..., :3].sum()) < 1e-4 * f2[..., :3].sum()
     hs.close(); hf.close()
 
