@@ -193,6 +193,13 @@ def test_c4_full_size_properties_on_the_device_built_tree():
     a, b = ctx.trace(neg), cf.trace(neg)
     assert np.array_equal(a["t"], b["t"]) and (a["prim"] != b["prim"]).mean() < 0.005 and (a["t"][a["prim"] != NH.MISS] < 0.04 + 1e-6).all()
     assert ((a["prim"] != NH.MISS) & (a["t"] < 0)).any()          # (some of them do hit behind the origin)
+    # directions with zero components (the general slab test of the quantised node step, Trav::box_step4q), also from points that lie
+    # exactly on node planes (vertices of the height field)
+    ax = np.zeros((6000, 8), np.float32); ax[:, 7] = np.inf; ax[:, 3] = 1e-4
+    ax[:, 0:3] = full[:6000, 0:3] + [0, 0.3, 0]
+    ax[:2000, 5] = -1; ax[2000:4000, 4] = 1; ax[4000:5000, 6] = -1; ax[5000:, 4] = np.float32(0.6); ax[5000:, 5] = np.float32(-0.8)
+    a, b = ctx.trace(ax), cf.trace(ax)
+    assert np.array_equal(a["t"], b["t"]) and (a["prim"] != b["prim"]).mean() < 0.005 and (a["prim"] != NH.MISS).mean() > 0.9
     assert abs(ff[..., :3].sum() - f2[..., :3].sum()) < 1e-4 * f2[..., :3].sum()
     hs.close(); hf.close()
 
