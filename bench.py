@@ -65,15 +65,18 @@ def film_tensor(ctx, torch):
     return torch.as_tensor(_Film(), device="cuda")
 
 
-def committed_traffic(args, kname, bvh):
+def committed_traffic(args, kname, bvh, launches_per_step=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload, tree and kernel (they cannot run
-    inside this process): profiles/r03_<workload>_traffic.json, else round 2's; (None, None) when none matches"""
+    inside this process): profiles/r03_<workload>_traffic.json, else round 2's; (None, None) when none matches (a file whose launch
+    count per step differs was taken with another schedule - one pipeline against two, say - and its launches are not these)"""
     if args.spp or args.c4_side:
         return None, None
     for rnd in ("r03", "r02"):
         tpath = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, args.workload))
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
+            if launches_per_step is not None and tj.get("launches") and abs(tj["launches"] - launches_per_step) > 0.05 * launches_per_step:
+                continue
             if tj.get("kernel") == kname and tj.get("bvh", bvh) == bvh:
                 return int(tj["traffic_bytes_per_launch"]), tj.get("valu_issue_busy")
     return None, None
@@ -500,7 +503,7 @@ def main():
     # HBM bytes per launch of the same kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, scratch/pmc.sh; the doubling
     # holds for scattered reads too: scratch/fetchprobe.hip, profiles/r02_fetchprobe.txt), which cannot run inside this
     # process: the committed measurement of this workload, tree and kernel, if there is one
-    traffic, issue = committed_traffic(args, kname, bvh)
+    traffic, issue = committed_traffic(args, kname, bvh, (st["extend_launches"] / args.steps) if wavefront else None)
     if traffic is not None and traffic < 0.5 * alg_bytes:
         roof_note = ("algorithmic bytes (SURVEY 8d) count every box and record test at full size; on this scene the nodes and records stay in L1/L2 "
                      "(traffic = HBM bytes per launch from the committed PMC passes), so frac is not an HBM fraction here: what bounds the kernel is vector-ALU issue "
@@ -510,6 +513,11 @@ def main():
         if survey_bytes:
             roof_note += ("; this kernel reads quantised nodes, so a node visit is counted at the node's %d bytes and not at SURVEY 8d's 32 B per box tested "
                           "(that count, comparable with earlier rounds, is achieved_at_32_bytes_per_box)" % int(st["extend_node_bytes"]))
+    if st.get("pipelines", 1) == 2:
+        roof_note += ("; the render call ran as TWO pipelines side by side (DESIGN.md 5, finding 41), each over half of the samples with a pool of its own: a trace launch covers half "
+                      "the slots and shares the GPU with the other pipeline's shade stage, ray sort or trace launch while it runs, so its duration - and with it frac, which is "
+                      "per launch - is not what the kernel reaches alone (NORI_HIP_PIPELINES=1: one pipeline, frac 0.57 on this workload, 11 % more time per step); "
+                      "whole_step_frac = the algorithmic bytes of all trace launches of a step over the step's time")
     out = {
         "metric": "Msamples/s (path_mis, whole node)", "value": round(total_samples / dt / 1e6, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -526,7 +534,11 @@ def main():
                      "launches_per_step": (round(st["extend_launches"] / args.steps, 1) if wavefront else 1), "algorithmic_bytes_per_launch": int(alg_bytes),
                      "boxes_tested_per_ray": round(st["boxes_tested"] / max(1.0, rays_rank), 2), "prims_tested_per_ray": round(st["prims_tested"] / max(1.0, rays_rank), 2),
                      "node_width": int(st["extend_width"]), "node_bytes": int(st["extend_node_bytes"]) if wavefront else None,
-                     "achieved_at_32_bytes_per_box": (round(survey_bytes / (kernel_ms * 1e-3) / 1e9, 1) if survey_bytes else None), "node_visits_per_ray": (round(st["extend_visits"] / max(1.0, st["extend_rays"]), 2) if wavefront else None)}),
+                     "achieved_at_32_bytes_per_box": (round(survey_bytes / (kernel_ms * 1e-3) / 1e9, 1) if survey_bytes else None), "node_visits_per_ray": (round(st["extend_visits"] / max(1.0, st["extend_rays"]), 2) if wavefront else None),
+                     "pipelines": int(st.get("pipelines", 1)),
+                     # the trace stage's algorithmic bytes of a whole step over the step's time (everything else a step does counts as time, not as bytes)
+                     "whole_step_frac": (round(alg_bytes * st["extend_launches"] / args.steps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if wavefront else None),
+                     "whole_step_frac_at_32_bytes_per_box": (round(survey_bytes * st["extend_launches"] / args.steps / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if (wavefront and survey_bytes) else None)}),
     }
     if secondary:
         out["secondary"] = secondary

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <thread>
 #include "nori_device.h"
 
 #pragma clang fp contract(off)
@@ -1084,7 +1085,8 @@ __device__ __forceinline__ void trace_wave4(const DevScene &sc, StackT &stk, flo
 // spills 78 of them, at three one.  Three is 1-2 % faster on the scenes that live in the caches (cbox 25.5 -> 24.9 ms, subsurface 92.0 ->
 // 90.4), four on the 10 M-triangle scene (367 against 373 ms: there the fourth wave hides more HBM latency than the spills cost).
 template <bool EXT, int WIDE = 0, int WAVES = 4, bool QUANT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_finish(DevScene sc, Pool pool, float4 *film, const unsigned int *q_live, WfCounters *cnt, DevStats *stats) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_finish(DevScene sc, Pool pool_1, float4 *film, const unsigned int *q_live_1, const WfCounters *cnt, DevStats *stats,
+                                                                                                        Pool pool_2, const unsigned int *q_live_2, const WfCounters *cnt_2) {
     // stack entries per lane in LDS (the staged rays of trace_wave4 want room too: four workgroups per CU, 40 KB each at most)
     constexpr int FIN_DEPTH = WIDE == 4 ? (QUANT ? 11 : 8) : LDS_DEPTH;
     typedef typename std::conditional<QUANT, LdsStack6T<FIN_DEPTH>, LdsStackT<FIN_DEPTH> >::type StackLds;
@@ -1093,11 +1095,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     __shared__ float4 tw_o[WIDE == 4 ? 4 * TW_RAYS : 1], tw_d[WIDE == 4 ? 4 * TW_RAYS : 1];
     __shared__ unsigned int tw_meta[WIDE == 4 ? 4 * TW_RAYS : 1], tw_occ[WIDE == 4 ? 4 * 64 : 1];
     __shared__ uint4 tw_hit[WIDE == 4 ? 4 * 64 : 1];
-    const unsigned int n = CN_LIVE(cnt);
+    // Two lists (cnt_2 != null): the tails of a render call's two pipelines (render_entry) run as one launch - the batches of the first
+    // pipeline's live list, then those of the second's, each with its own pool.  Which list a batch belongs to is wave-uniform.
+    const unsigned int n_1 = CN_LIVE(cnt), n_2 = cnt_2 ? CN_LIVE(cnt_2) : 0u;
     const unsigned int lane = threadIdx.x & 63u;
-    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, n_batches = (n + 63u) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6, nb_1 = (n_1 + 63u) >> 6, n_batches = nb_1 + ((n_2 + 63u) >> 6);
     unsigned int batch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // wave-uniform
-    unsigned int cursor = batch << 6, end = (cursor + 64u < n) ? cursor + 64u : n;
+    unsigned int cursor = 0, end = 0;
+#define ND_FIN_BATCH() do { const bool s_ = batch >= nb_1; const unsigned int n_ = s_ ? n_2 : n_1; cursor = (s_ ? batch - nb_1 : batch) << 6; end = (cursor + 64u < n_) ? cursor + 64u : n_; } while (0)
+    ND_FIN_BATCH();
     uint2 stack_spill[(WIDE == 8 ? ND_STACK8 : ND_STACK) - FIN_DEPTH];
     StackLds stk; stk.spill = stack_spill; stk.attach(lds_stack, threadIdx.x >> 6, lane);
     Counters ctr = {0, 0, 0, 0, 0, 0}; unsigned int n_invalid = 0;
@@ -1111,6 +1117,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         const unsigned long long dead = __ballot(!alive);
         if (dead && batch < n_batches) {
             const unsigned int idx = cursor + __builtin_amdgcn_mbcnt_hi((unsigned int) (dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int) dead, 0u));
+            const bool second = batch >= nb_1;                                // wave-uniform
+            Pool pool; const unsigned int *q_live = second ? q_live_2 : q_live_1;
+            pool.li = second ? pool_2.li : pool_1.li; pool.hit = second ? pool_2.hit : pool_1.hit; pool.pix = second ? pool_2.pix : pool_1.pix; pool.sh_c = second ? pool_2.sh_c : pool_1.sh_c;
+            pool.ray_o = second ? pool_2.ray_o : pool_1.ray_o; pool.ray_d = second ? pool_2.ray_d : pool_1.ray_d; pool.thr = second ? pool_2.thr : pool_1.thr; pool.rng = second ? pool_2.rng : pool_1.rng;
+            pool.sh_o = second ? pool_2.sh_o : pool_1.sh_o; pool.sh_d = second ? pool_2.sh_d : pool_1.sh_d;
+            pool.sv_o = second ? pool_2.sv_o : pool_1.sv_o; pool.sv_d = second ? pool_2.sv_d : pool_1.sv_d; pool.sv_h = second ? pool_2.sv_h : pool_1.sv_h;
             if (!alive && idx < end) {
                 slot = q_live[idx];
                 const float4 L = pool.li[slot];
@@ -1150,8 +1162,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
                 }
             }
             cursor += (unsigned int) __popcll(dead);
-            if (cursor >= end) { batch += n_waves; cursor = batch << 6; end = (cursor + 64u < n) ? cursor + 64u : n; }
+            if (cursor >= end) { batch += n_waves; ND_FIN_BATCH(); }
         }
+#undef ND_FIN_BATCH
         if (__ballot(alive) == 0ull) { if (batch >= n_batches) break; else continue; }
         if (WIDE == 4) {
             // one bounce: the hit is in registers; the wave traces its shadow rays and next rays together
@@ -1451,6 +1464,13 @@ struct NoriHipContext {
     bool merge_trace = true;          // one trace launch per iteration for shadow and extend rays (NORI_HIP_MERGE=0: two launches)
     bool profile = false;             // NORI_HIP_PROFILE=1: step statistics of the trace stages, printed by nori_hip_stats
     int thr_box = 1, thr_prim = 1, thr_refill = 12;   // k_trace_pool step thresholds (lanes), NORI_HIP_THR
+    // Two pipelines (render_entry): a render call over a tree beyond the caches is cut into two halves of its sample range that run side by
+    // side, each through its own pool and stream - this context and its `twin`, which borrows the scene, the film and every setting and owns
+    // only what a pipeline needs for itself (stream, pool, counters, live list, sort buffers, events).
+    int pipelines = -1;               // NORI_HIP_PIPELINES: 1 or 2; -1 = two for trees beyond the caches, one otherwise (measured, DESIGN finding 41)
+    NoriHipContext *twin = nullptr; bool is_twin = false;
+    bool twin_tail_merged = true;     // NORI_HIP_TWIN_TAIL=separate: each pipeline launches its own tail kernel
+    hipEvent_t twin_go = nullptr, twin_done = nullptr;
     // adds the elapsed time of the recorded extend launches to ext_ms_acc (waits for them)
     int fold_ext_events() {
         for (size_t k = 0; k + 1 < ext_used; k += 2) {
@@ -1462,6 +1482,11 @@ struct NoriHipContext {
         return NORI_HIP_OK;
     }
     void free_scene() {
+        if (is_twin) {           // borrowed from the context it belongs to: forget, do not free
+            d_nodes4 = nullptr; d_nodes8 = nullptr; d_nodes4q = nullptr; d_env_cdf = nullptr; d_nodes = nullptr; d_prims = nullptr; d_shade = d_light = nullptr; d_shapes = nullptr;
+            d_emitters = nullptr; d_cdf = nullptr; d_film = nullptr; d_textures = nullptr; d_tex_data = nullptr; d_filt = nullptr; have_scene = false;
+            return;
+        }
         hipFree(d_nodes4); d_nodes4 = nullptr; n_nodes4 = 0;
         hipFree(d_nodes8); d_nodes8 = nullptr; n_nodes8 = 0;
         hipFree(d_nodes4q); d_nodes4q = nullptr;
@@ -1535,6 +1560,8 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_BOX2")) { int v = atoi(e); if (v >= 0 && v <= 64) c->box2 = v; }
     if (const char *e = getenv("NORI_HIP_COMPACT")) c->compact = atoi(e) != 0;
     if (const char *e = getenv("NORI_HIP_FINISH")) c->finish_below = (unsigned int) atol(e);
+    if (const char *e = getenv("NORI_HIP_PIPELINES")) { int v = atoi(e); if (v == 1 || v == 2) c->pipelines = v; }
+    if (const char *e = getenv("NORI_HIP_TWIN_TAIL")) c->twin_tail_merged = std::string(e) != "separate";
     if (const char *e = getenv("NORI_HIP_FINISH_WAVES")) { int v = atoi(e); if (v == 3 || v == 4) c->finish_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
@@ -1591,6 +1618,9 @@ int nori_hip_destroy(NoriHipContext *ctx) {
     if (!ctx) return NORI_HIP_OK;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->twin) { nori_hip_destroy(ctx->twin); ctx->twin = nullptr; }
+    if (ctx->twin_go) hipEventDestroy(ctx->twin_go);
+    if (ctx->twin_done) hipEventDestroy(ctx->twin_done);
     ctx->free_scene();
     hipFree(ctx->d_counter); hipFree(ctx->d_stats); hipFree(ctx->d_tiles); hipFree(ctx->d_cnt); hipFree(ctx->pool_mem);
     hipFree(ctx->d_qlive); hipFree(ctx->d_filt); hipFree(ctx->d_sort);
@@ -1966,7 +1996,30 @@ int nori_hip_li_samples(NoriHipContext *ctx, size_t n, const int32_t *px, const 
     return NORI_HIP_OK;
 }
 
-static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end);
+// What a pipeline hands back instead of launching its tail kernel
+struct TailHandoff { bool valid = false; Pool pool; const unsigned int *q_live = nullptr; const WfCounters *cnt = nullptr; unsigned int n_upper = 0; bool wide = false, wide8 = false, big_tree = false; };
+// The tail kernel over one live list, or over the lists of two pipelines (cnt_2 != null)
+static int launch_finish(NoriHipContext *ctx, hipStream_t stream, bool wide, bool wide8, bool big_tree, Pool p1, const unsigned int *q1, const WfCounters *c1, unsigned int n_upper1,
+                         Pool p2, const unsigned int *q2, const WfCounters *c2, unsigned int n_upper2) {
+    const bool fin3 = wide && (ctx->finish_waves ? ctx->finish_waves == 3 : !big_tree);            // the tail kernel built for three waves per SIMD (see k_finish)
+    const unsigned fin_waves = fin3 ? 3u : 4u;
+    const unsigned long long n_upper = (unsigned long long) n_upper1 + n_upper2 + (c2 ? 64u : 0u);
+    const dim3 fin_grid(std::max(1u, std::min<unsigned>((unsigned) ((n_upper + 255) / 256), (unsigned) ctx->n_cus * fin_waves)));
+#define ND_FIN(K) hipLaunchKernelGGL(K, fin_grid, dim3(256), 0, stream, ctx->sc, p1, ctx->d_film, q1, c1, ctx->d_stats, p2, q2, c2)
+    if (ctx->ext && wide && fin3) ND_FIN((k_finish<true, 4, 3>));
+    else if (ctx->ext && wide) ND_FIN((k_finish<true, 4>));
+    else if (ctx->ext) ND_FIN(k_finish<true>);
+    else if (wide8) ND_FIN((k_finish<false, 8>));
+    else if (wide && !fin3 && ctx->sc.nodes4q && ctx->sc.leaf2) ND_FIN((k_finish<false, 4, 4, true>));
+    else if (wide && fin3) ND_FIN((k_finish<false, 4, 3>));
+    else if (wide) ND_FIN((k_finish<false, 4>));
+    else ND_FIN(k_finish<false>);
+#undef ND_FIN
+    HIPCHK(hipGetLastError());
+    return NORI_HIP_OK;
+}
+
+static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end, TailHandoff *tail = nullptr);
 
 int nori_hip_bsdf_vectors(NoriHipContext *ctx, const NoriHipShape *bsdf, size_t n, const float *wi, const float *sample, const float *sample2, const float *wo, float *out) {
     CTXCHK(ctx);
@@ -2023,15 +2076,91 @@ int nori_hip_pcg32(NoriHipContext *ctx, uint64_t state, uint64_t seq, size_t n, 
     return NORI_HIP_OK;
 }
 
+// does a render call of this context go through the wavefront stages (else: the single persistent kernel)
+static bool uses_stages(const NoriHipContext *ctx) {
+    const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS, direct = ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS;
+    // Scenes with images or subsurface shapes: the stages when the scene has subsurface shapes (their probe rays go through the trace
+    // stage) and a tree with inner nodes, else the single kernel (image lookups on a few dozen primitives: measured faster).
+    const bool ext_stages = ctx->has_ss && ctx->wide && ctx->d_nodes4 != nullptr && ctx->merge_trace;
+    return !(ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced && !ext_stages) || (ctx->has_ss && !ext_stages) || mats || direct);
+}
+// "big tree": nodes and records against the Infinity Cache (256 MiB), see render_impl
+static bool tree_beyond_caches(const NoriHipContext *ctx) {
+    const size_t tree_bytes = (size_t) (ctx->n_nodes8 ? (size_t) ctx->n_nodes8 * 128 : ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
+    return tree_bytes > ((size_t) 192 << 20);
+}
+// The twin takes over everything the context knows about the scene and its settings and keeps what is its own.
+static void twin_borrow(NoriHipContext *t, const NoriHipContext *c) {
+    struct Own {
+        hipStream_t stream; unsigned long long *d_counter; DevStats *d_stats; int *d_tiles; hipEvent_t ev0, ev1; NoriHipStats stats;
+        Pool pool, pool_b; void *pool_mem; unsigned int pool_alloc; unsigned int *d_sort; size_t sort_temp_bytes; unsigned int *d_qlive; WfCounters *d_cnt;
+        unsigned int *h_ring; hipEvent_t ring_ev[4]; std::vector<hipEvent_t> ext_ev; size_t ext_used; double ext_ms_acc; uint64_t ext_launches;
+    } own = {t->stream, t->d_counter, t->d_stats, t->d_tiles, t->ev0, t->ev1, t->stats, t->pool, t->pool_b, t->pool_mem, t->pool_alloc, t->d_sort, t->sort_temp_bytes, t->d_qlive, t->d_cnt,
+             t->h_ring, {t->ring_ev[0], t->ring_ev[1], t->ring_ev[2], t->ring_ev[3]}, std::move(t->ext_ev), t->ext_used, t->ext_ms_acc, t->ext_launches};
+    *t = *c;
+    t->stream = own.stream; t->d_counter = own.d_counter; t->d_stats = own.d_stats; t->d_tiles = own.d_tiles; t->ev0 = own.ev0; t->ev1 = own.ev1; t->stats = own.stats;
+    t->pool = own.pool; t->pool_b = own.pool_b; t->pool_mem = own.pool_mem; t->pool_alloc = own.pool_alloc; t->d_sort = own.d_sort; t->sort_temp_bytes = own.sort_temp_bytes;
+    t->d_qlive = own.d_qlive; t->d_cnt = own.d_cnt; t->h_ring = own.h_ring; for (int i = 0; i < 4; ++i) t->ring_ev[i] = own.ring_ev[i];
+    t->ext_ev = std::move(own.ext_ev); t->ext_used = own.ext_used; t->ext_ms_acc = own.ext_ms_acc; t->ext_launches = own.ext_launches;
+    t->twin = nullptr; t->is_twin = true; t->twin_go = nullptr; t->twin_done = nullptr; t->pipelines = 1;
+}
+// One render call.  Over a tree beyond the caches the wavefront stages run as two pipelines side by side (NoriHipContext::pipelines): the
+// first half of the sample range here, the second half on the twin's stream, driven by a thread of its own.  A stage of one pipeline then
+// runs while the other pipeline is between stages or in a stage that leaves most of the machine idle (the shade stage and the ray sort are
+// bound by memory, the trace stage's last waves by their longest rays).  Every sample is the same sample as in one pipeline (its random
+// numbers depend on pixel and sample index only); the film is shared and summed by atomics as before.  The context's stream waits for the
+// twin's, so for the caller the call completes in stream order as it always did.
+static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end) {
+    SCENECHK(ctx);
+    const int np = ctx->pipelines > 0 ? ctx->pipelines : (tree_beyond_caches(ctx) ? 2 : 1);
+    if (np < 2 || ctx->is_twin || !uses_stages(ctx) || spp_end - spp_begin < 2 || spp_begin < 0) return render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
+    if (!ctx->twin) {
+        NoriHipContext *t = new NoriHipContext();
+        t->device = ctx->device; t->is_twin = true;
+        const int rc = create_impl(t, ctx->device);
+        if (rc != NORI_HIP_OK) { const std::string why = g_err; nori_hip_destroy(t); g_err = why; return rc; }
+        ctx->twin = t;
+    }
+    if (!ctx->twin_go) { HIPCHK(hipEventCreateWithFlags(&ctx->twin_go, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->twin_done, hipEventDisableTiming)); }
+    NoriHipContext *t = ctx->twin;
+    twin_borrow(t, ctx);
+    const int mid = spp_begin + (spp_end - spp_begin + 1) / 2;             // (unequal halves measured worse: 56 / 62 / 75 % here: +1 / +6 / +7 % per step)
+    HIPCHK(hipEventRecord(ctx->twin_go, ctx->stream));                    // what the caller queued before this call (a film clear, say) comes first for both
+    HIPCHK(hipStreamWaitEvent(t->stream, ctx->twin_go, 0));
+    // The two pipelines reach their tails within a millisecond of each other.  Two tail kernels side by side get in each other's way (48 and
+    // 65 ms where one launch over all the paths takes 48): each pipeline hands its live list back instead, and ONE launch finishes both.
+    const bool merged_tail = ctx->twin_tail_merged;
+    TailHandoff h1, h2;
+    int rc2 = NORI_HIP_OK; std::string err2;
+    std::thread th([&]() { rc2 = render_impl(t, tiles_xyxy, n_tiles, mid, spp_end, merged_tail ? &h2 : nullptr); if (rc2 != NORI_HIP_OK) err2 = g_err; });
+    int rc1 = render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, mid, merged_tail ? &h1 : nullptr);
+    std::string err1 = rc1 != NORI_HIP_OK ? g_err : std::string();
+    th.join();
+    (void) hipSetDevice(ctx->device);
+    if (hipEventRecord(ctx->twin_done, t->stream) == hipSuccess) (void) hipStreamWaitEvent(ctx->stream, ctx->twin_done, 0);
+    else { (void) hipGetLastError(); (void) hipStreamSynchronize(t->stream); }
+    if (rc1 == NORI_HIP_OK && rc2 == NORI_HIP_OK && (h1.valid || h2.valid)) {
+        const TailHandoff &a = h1.valid ? h1 : h2;
+        const bool both = h1.valid && h2.valid;
+        rc1 = launch_finish(ctx, ctx->stream, a.wide, a.wide8, a.big_tree, a.pool, a.q_live, a.cnt, a.n_upper, both ? h2.pool : a.pool, both ? h2.q_live : nullptr, both ? h2.cnt : nullptr, both ? h2.n_upper : 0u);
+        if (rc1 != NORI_HIP_OK) err1 = g_err;
+    }
+    (void) hipEventRecord(ctx->ev1, ctx->stream);                         // render_ms covers both pipelines
+    ctx->stats.pipelines = 2;
+    ctx->trace_width = std::max(ctx->trace_width, t->trace_width); ctx->trace_node_bytes = std::max(ctx->trace_node_bytes, t->trace_node_bytes);
+    if (rc1 != NORI_HIP_OK) return fail(rc1, err1);
+    if (rc2 != NORI_HIP_OK) return fail(rc2, err2);
+    return NORI_HIP_OK;
+}
 int nori_hip_render(NoriHipContext *ctx, int x0, int y0, int x1, int y1, int spp_begin, int spp_end) {
     const int t[4] = {x0, y0, x1, y1};
-    return render_impl(ctx, t, 1, spp_begin, spp_end);
+    return render_entry(ctx, t, 1, spp_begin, spp_end);
 }
 int nori_hip_render_tiles(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end) {
-    return render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
+    return render_entry(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
 }
 
-static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end) {
+static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end, TailHandoff *tail) {
     SCENECHK(ctx);
     const int W = ctx->sc.cam.width, H = ctx->sc.cam.height;
     if (!tiles_xyxy || n_tiles < 1 || n_tiles > ND_MAX_TILES) return fail(NORI_HIP_EINVAL, "tile list is null, empty or longer than " + std::to_string(ND_MAX_TILES));
@@ -2062,12 +2191,9 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         job.tiles = reinterpret_cast<const int4 *>(ctx->d_tiles); job.patch_first = reinterpret_cast<const unsigned int *>(ctx->d_tiles + 4 * ND_MAX_TILES);
     }
     HIPCHK(hipMemsetAsync(ctx->d_counter, 0, sizeof(unsigned long long), ctx->stream));
-    ctx->trace_width = 0; ctx->trace_node_bytes = 0;
+    ctx->trace_width = 0; ctx->trace_node_bytes = 0; ctx->stats.pipelines = 1;
     const bool mats = ctx->integrator == NORI_HIP_INTEGRATOR_PATH_MATS, direct = ctx->integrator == NORI_HIP_INTEGRATOR_DIRECT_MIS;
-    // Scenes with images or subsurface shapes: the stages when the scene has subsurface shapes (their probe rays go through the trace
-    // stage) and a tree with inner nodes, else the single kernel (image lookups on a few dozen primitives: measured faster).
-    const bool ext_stages = ctx->has_ss && ctx->wide && ctx->d_nodes4 != nullptr && ctx->merge_trace;
-    if (ctx->pipeline == 0 || (ctx->ext && !ctx->pipeline_forced && !ext_stages) || (ctx->has_ss && !ext_stages) || mats || direct) {
+    if (!uses_stages(ctx)) {
         // single persistent kernel with per-lane path regeneration
         unsigned long long chunks = (job.total + MEGA_THREADS - 1) / MEGA_THREADS;
         const int MW = ctx->mega_waves;
@@ -2096,8 +2222,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     // issuing, and a few defaults change with that (measured on the 10 M-triangle workload): rays are ordered before every trace
     // launch, no speculative traversal, no second box step per trip, and half instead of three eighths of the call's paths in the pool
     // (fewer, larger launches: the stage's ramp-up and drain are paid less often).
-    const size_t tree_bytes = (size_t) (ctx->n_nodes8 ? (size_t) ctx->n_nodes8 * 128 : ctx->n_nodes4 ? (size_t) ctx->n_nodes4 * 128 : (size_t) ctx->n_nodes * 64) + (size_t) ctx->n_prims * sizeof(NoriHipPrim);
-    const bool big_tree = tree_bytes > ((size_t) 192 << 20);
+    const bool big_tree = tree_beyond_caches(ctx);
     const unsigned int pool_cap = ctx->pool_slots ? ctx->pool_slots : (1u << 23);
     unsigned int P = pool_cap;
     if (!ctx->pool_slots) P = (unsigned int) std::min<unsigned long long>(pool_cap, std::max<unsigned long long>(1ull << 20, ((big_tree ? job.total / 2 : ctx->has_ss ? job.total / 4 : job.total * 3 / 8) + 65535) & ~65535ull));     // (scenes with subsurface shapes: 13 pool arrays instead of 10, a quarter measured better: 89.8 against 92.7 ms)
@@ -2232,18 +2357,10 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
             n_upper = ctx->h_ring[(it - 3) & 3];
             if (n_upper == 0) break;
             if (n_upper < finish_below) {
-                // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch
-                const bool fin3 = wide && (ctx->finish_waves ? ctx->finish_waves == 3 : !big_tree);            // the tail kernel built for three waves per SIMD (see k_finish)
-                const unsigned fin_waves = fin3 ? 3u : 4u;
-                const dim3 fin_grid(std::max(1u, std::min<unsigned>((n_upper + 255) / 256, (unsigned) ctx->n_cus * fin_waves)));
-                if (ctx->ext && wide && fin3) hipLaunchKernelGGL((k_finish<true, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (ctx->ext && wide) hipLaunchKernelGGL((k_finish<true, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (ctx->ext) hipLaunchKernelGGL(k_finish<true>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (wide8) hipLaunchKernelGGL((k_finish<false, 8>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (wide && !fin3 && ctx->sc.nodes4q && ctx->sc.leaf2) hipLaunchKernelGGL((k_finish<false, 4, 4, true>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (wide && fin3) hipLaunchKernelGGL((k_finish<false, 4, 3>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else if (wide) hipLaunchKernelGGL((k_finish<false, 4>), fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
-                else hipLaunchKernelGGL(k_finish<false>, fin_grid, dim3(256), 0, ctx->stream, ctx->sc, pools[pi], ctx->d_film, (const unsigned int *) ctx->d_qlive, c, ctx->d_stats);
+                // fewer live paths than the threshold (which also means the work counter is exhausted): finish them in one launch -
+                // or leave them to the caller, who finishes both pipelines' paths together (render_entry)
+                if (tail) { tail->valid = true; tail->pool = pools[pi]; tail->q_live = ctx->d_qlive; tail->cnt = c; tail->n_upper = n_upper; tail->wide = wide; tail->wide8 = wide8; tail->big_tree = big_tree; }
+                else { const int rcf = launch_finish(ctx, ctx->stream, wide, wide8, big_tree, pools[pi], ctx->d_qlive, c, n_upper, pools[pi], nullptr, nullptr, 0u); if (rcf != NORI_HIP_OK) return rcf; }
                 HIPCHK(hipGetLastError());
                 ++it;
                 break;
@@ -2364,6 +2481,11 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<DevStats> stripes(ND_STRIPES);
     HIPCHK(hipMemcpy(stripes.data(), ctx->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
+    if (ctx->twin) {                  // the second pipeline's counters and trace launches count with the first's
+        HIPCHK(hipStreamSynchronize(ctx->twin->stream));
+        stripes.resize(2 * ND_STRIPES);
+        HIPCHK(hipMemcpy(stripes.data() + ND_STRIPES, ctx->twin->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
+    }
     DevStats ds; std::memset(&ds, 0, sizeof(ds));
     for (const DevStats &t : stripes) {
         ds.ext_rays += t.ext_rays; ds.ext_nodes += t.ext_nodes; ds.ext_prims += t.ext_prims; ds.ext_visits += t.ext_visits; ds.culled += t.culled; ds.dropped += t.dropped;
@@ -2376,6 +2498,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     ctx->stats.boxes_tested = ds.nodes; ctx->stats.prims_tested = ds.prims;
     ctx->fold_ext_events();
     ctx->stats.extend_ms = ctx->ext_ms_acc; ctx->stats.extend_launches = ctx->ext_launches;
+    if (ctx->twin) { ctx->twin->fold_ext_events(); ctx->stats.extend_ms += ctx->twin->ext_ms_acc; ctx->stats.extend_launches += ctx->twin->ext_launches; }
     ctx->stats.extend_rays = ds.ext_rays; ctx->stats.extend_boxes = ds.ext_nodes; ctx->stats.extend_prims = ds.ext_prims;
     ctx->stats.extend_visits = ds.ext_visits; ctx->stats.extend_width = ctx->trace_width; ctx->stats.extend_node_bytes = ctx->trace_node_bytes; ctx->stats.shadow_rays_culled = ds.culled; ctx->stats.ss_paths_dropped = ds.dropped;
     if (ctx->profile) {
@@ -2393,6 +2516,10 @@ int nori_hip_reset_stats(NoriHipContext *ctx) {
     CTXCHK(ctx);
     HIPCHK(hipMemsetAsync(ctx->d_stats, 0, ND_STRIPES * sizeof(DevStats), ctx->stream));
     ctx->fold_ext_events(); ctx->ext_ms_acc = 0.0; ctx->ext_launches = 0;
+    if (ctx->twin) {
+        HIPCHK(hipMemsetAsync(ctx->twin->d_stats, 0, ND_STRIPES * sizeof(DevStats), ctx->twin->stream));
+        ctx->twin->fold_ext_events(); ctx->twin->ext_ms_acc = 0.0; ctx->twin->ext_launches = 0;
+    }
     return NORI_HIP_OK;
 }
 int nori_hip_stream(NoriHipContext *ctx, void **stream) { CTXCHK(ctx); if (stream) *stream = ctx->stream; return NORI_HIP_OK; }

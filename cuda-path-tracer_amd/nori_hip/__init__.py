@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("boxes_tested", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint64), ("render_ms", C.c_double),
                 ("extend_ms", C.c_double), ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("extend_boxes", C.c_uint64),
                 ("extend_prims", C.c_uint64), ("extend_visits", C.c_uint64), ("extend_width", C.c_uint64), ("shadow_rays_culled", C.c_uint64),
-                ("ss_paths_dropped", C.c_uint64), ("extend_node_bytes", C.c_uint64)]
+                ("ss_paths_dropped", C.c_uint64), ("extend_node_bytes", C.c_uint64), ("pipelines", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("lmin", "<f4", 3), ("lmax", "<f4", 3), ("rmin", "<f4", 3), ("rmax", "<f4", 3), ("left", "<u4"), ("right", "<u4"),

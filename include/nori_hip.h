@@ -201,6 +201,9 @@ typedef struct NoriHipStats {
                                       with full weight (a bias, counted here so that it is never silent; 0 on every scene the reference ships) */
     uint64_t extend_node_bytes;    /* size of the node the trace stage of the last render fetched per visit: 64 (two boxes, or four quantised
                                       boxes: device-built trees with placed leaves, NORI_HIP_QUANT) or 128 (four float boxes, eight quantised) */
+    uint64_t pipelines;            /* how the last render call ran its wavefront stages: 1, or 2 = as two pipelines side by side, each over half of the
+                                      call's sample range with a pool and stream of its own (trees beyond the caches, NORI_HIP_PIPELINES); every counter
+                                      above covers both, and extend_ms / extend_launches are then launches that shared the GPU with the other pipeline's */
 } NoriHipStats;
 
 typedef struct NoriHipContext NoriHipContext;

@@ -171,9 +171,13 @@ def test_c4_full_size_properties_on_the_device_built_tree():
     ff, sf = cf.read_film(), cf.stats()
     assert sf["extend_node_bytes"] == 128
     assert np.array_equal(ff[..., 3], f2[..., 3])
+    # (a render of this scene runs as two pipelines side by side, DESIGN.md finding 41: a pixel's samples reach the film in an order that
+    # differs from run to run more than with one, so "the same pixel" is: the same sums up to the order of the additions)
+    assert s2["pipelines"] == 2 and sf["pipelines"] == 2
     same = (ff == f2).all(-1).mean()
-    print("full-size C4, quantised against float nodes: %.5f of the pixels bit-identical" % same)
-    assert same > 0.995, same
+    close = np.isclose(ff, f2, rtol=1e-5, atol=1e-6).all(-1).mean()
+    print("full-size C4, quantised against float nodes: %.5f of the pixels bit-identical, %.5f equal up to summation order" % (same, close))
+    assert same > 0.98 and close > 0.995, (same, close)
     # ray by ray (nori_hip_trace walks the quantised nodes with cut stack entries in ctx, the two-box float nodes in cf): the same
     # distance for every ray, bit for bit, and another primitive only where two tie at that distance
     bounce = rays.copy(); bounce[:, 0:3] = full[:, 0:3]; bounce[:, 3] = 1e-4

@@ -245,6 +245,14 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_FINISH="20000", NORI_HIP_FINISH_WAVES="3", NORI_HIP_POOL="24576"),
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0"),                                 # trace stage over the 64-byte two-box nodes
                 dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_WIDE="0", NORI_HIP_SPEC="0", NORI_HIP_POOL="4096")]
+    # two pipelines side by side, each over half of the sample range (the default for trees beyond the caches): one tail launch over both
+    # live lists, a tail kernel each, and a call that is all tail
+    twin = [dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_PIPELINES="2"),
+            dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_PIPELINES="2", NORI_HIP_POOL="4096", NORI_HIP_FINISH="900"),
+            dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_PIPELINES="2", NORI_HIP_TWIN_TAIL="separate", NORI_HIP_POOL="1000"),
+            dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_PIPELINES="2", NORI_HIP_SORT="1", NORI_HIP_FINISH="20000"),
+            dict(NORI_HIP_PIPELINE="wavefront", NORI_HIP_PIPELINES="2", NORI_HIP_FINISH="1", NORI_HIP_WIDE="0")]
+    configs += twin
     # Any-hit rays normally enter the nearer child first (the answer does not depend on the order, the number of records tested
     # before an occluder is found does, and the nearer of two children is not always the nearest of four).  For the record-count
     # comparison below they walk the tree in the reference's order like closest-hit rays do.
@@ -259,6 +267,8 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
                 del os.environ[k]
         ctx.reset_stats(); ctx.render(0, spp)
         films.append(ctx.read_film()); stats.append(ctx.stats())
+        # (extend_launches == 0: the call went through the single kernel, which has no second pipeline - subsurface shapes over two-box nodes)
+        assert stats[-1]["pipelines"] == (2 if env.get("NORI_HIP_PIPELINES") == "2" and stats[-1]["extend_launches"] > 0 else 1), (env, stats[-1]["pipelines"])
         hs.close()
     # and once with the default any-hit order: the same film, the same rays
     hs = NH.HostScene(os.path.join(SCENES, {**SCENE_XML, **IMAGE_XML}[name]), W, H, spp)
@@ -282,6 +292,52 @@ def test_wavefront_and_single_kernel_pipelines_agree(name):
     boxes = [st["boxes_tested"] for st in stats]
     assert max(boxes) <= 1.25 * min(boxes), boxes
     assert stats[0]["camera_samples"] == W * H * spp and stats[0]["iterations"] > 10
+
+
+def test_two_pipelines_per_render_call(loaded):
+    """NORI_HIP_PIPELINES=2: a render call cut into two halves of its sample range that run side by side on two streams and share the
+    film.  Every sample is the sample one pipeline would have drawn, so counts are equal and films agree up to summation order; tile
+    lists, odd ranges, a range of one sample (one pipeline) and stream order with the caller's other work (clear, read) hold."""
+    W, H = 64, 64
+    hs1, c1 = loaded("cbox", W, H)
+    c1.clear_film(); c1.reset_stats(); c1.render(0, 7)
+    f1, s1 = c1.read_film(), c1.stats()
+    assert s1["pipelines"] == 1
+    os.environ.update({"NORI_HIP_PIPELINES": "2", "NORI_HIP_POOL": "2048"})
+    try:
+        hs2 = NH.HostScene(os.path.join(SCENES, SCENE_XML["cbox"]), W, H, 4)
+        c2 = hs2.preprocess()
+    finally:
+        del os.environ["NORI_HIP_PIPELINES"], os.environ["NORI_HIP_POOL"]
+    for _ in range(2):                                                         # (the second time the twin exists already)
+        c2.clear_film(); c2.reset_stats(); c2.render(0, 7)
+        f2, s2 = c2.read_film(), c2.stats()
+        assert s2["pipelines"] == 2
+        assert np.array_equal(f2[:, :, 3], f1[:, :, 3]) and np.allclose(f2, f1, rtol=1e-4, atol=1e-5)
+        for k in ("camera_samples", "closest_rays", "shadow_rays", "shadow_rays_culled", "invalid_samples", "prims_tested"):
+            assert s2[k] == s1[k], (k, s2[k], s1[k])
+        assert s2["extend_launches"] > s1["extend_launches"]               # (both pipelines' trace launches are counted)
+    # accumulation over calls, a one-sample call in between, ragged tile lists
+    c2.clear_film(); c2.render(0, 3); c2.render(3, 4)
+    assert c2.stats()["pipelines"] == 1
+    c2.render_tiles(4, 7, [(0, 0, 13, 9), (13, 0, W, 9), (0, 9, 50, H), (50, 9, W, 41), (50, 41, W, H)])
+    f3 = c2.read_film()
+    assert c2.stats()["pipelines"] == 2
+    assert np.array_equal(f3[:, :, 3], f1[:, :, 3]) and np.allclose(f3, f1, rtol=1e-4, atol=1e-5)
+    # a new scene on the same context: the twin follows
+    hs3 = NH.HostScene(os.path.join(SCENES, SCENE_XML["table"]), W, H, 4)
+    hs2.close()
+    os.environ["NORI_HIP_PIPELINES"] = "2"
+    try:
+        c3 = hs3.preprocess()
+    finally:
+        del os.environ["NORI_HIP_PIPELINES"]
+    c3.clear_film(); c3.render(0, 4)
+    hs4, c4 = loaded("table", W, H)
+    c4.clear_film(); c4.render(0, 4)
+    a, b = c3.read_film(), c4.read_film()
+    assert np.array_equal(a[:, :, 3], b[:, :, 3]) and np.allclose(a, b, rtol=1e-4, atol=1e-5)
+    hs3.close()
 
 
 @pytest.mark.parametrize("name", ["table_microfacet", "dragon", "cbox_subsurface"])
