@@ -383,7 +383,14 @@ __global__ void k_pool_init(Pool pool, unsigned int n, WfCounters *cnt) {
     }
     if (i == 0) CN_LIVE(cnt) = 0u;
 }
-__global__ void k_iter_begin(WfCounters *cnt) { CN_LIVE(cnt) = 0u; for (int q = 0; q < 8; ++q) CN_DYN(cnt, q) = 0u; }
+// (`report`: a word of pinned host memory that receives the live count the previous iteration's shade stage left - the host reads it three
+// iterations later, after the event recorded behind this kernel.  A store from here instead of a 4-byte hipMemcpyAsync per iteration: the
+// runtime's copy kernels of a process share one queue, where the copy of one pipeline waited behind the other pipeline's - 0.67 ms on
+// average per iteration with two pipelines)
+__global__ void k_iter_begin(WfCounters *cnt, unsigned int *report) {
+    if (report) { *report = CN_LIVE(cnt); __threadfence_system(); }
+    CN_LIVE(cnt) = 0u; for (int q = 0; q < 8; ++q) CN_DYN(cnt, q) = 0u;
+}
 
 // Once the work counter is exhausted the live paths thin out by about a quarter per bounce, while every stage still
 // sweeps the whole pool.  When fewer than half of the slots are live the host has them packed into the front of a
@@ -2296,7 +2303,9 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     unsigned int n_upper = P;              // upper bound of the live-slot count (a ring value that is three iterations old)
     uint64_t it = 0;
     for (;; ++it) {
-        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c);
+        // the live count of iteration it - 1 goes to the host ring here (k_iter_begin), its event right behind
+        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, ctx->stream, c, it > 0 ? ctx->h_ring + ((it - 1) & 3) : (unsigned int *) nullptr);
+        if (it > 0) HIPCHK(hipEventRecord(ctx->ring_ev[(it - 1) & 3], ctx->stream));
         hipLaunchKernelGGL(shade_kern, dim3(shade_blocks), dim3(256), shade_lds, ctx->stream, ctx->sc, pools[pi], P, job, ctx->d_film, ctx->d_qlive, c, ctx->d_counter, ctx->d_stats,
                            fused_keys ? ctx->d_sort : (unsigned int *) nullptr);
         {
@@ -2350,8 +2359,6 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
         HIPCHK(hipGetLastError());
         // the live count comes back through a 4-deep ring of pinned words, so the host runs at most three iterations
         // ahead of the device and never waits on the iteration it has just queued
-        HIPCHK(hipMemcpyAsync(&ctx->h_ring[it & 3], &CN_LIVE(c), sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipEventRecord(ctx->ring_ev[it & 3], ctx->stream));
         if (it >= 3) {
             HIPCHK(hipEventSynchronize(ctx->ring_ev[(it - 3) & 3]));
             n_upper = ctx->h_ring[(it - 3) & 3];
