@@ -1474,7 +1474,13 @@ struct NoriHipContext {
     // Two pipelines (render_entry): a render call over a tree beyond the caches is cut into two halves of its sample range that run side by
     // side, each through its own pool and stream - this context and its `twin`, which borrows the scene, the film and every setting and owns
     // only what a pipeline needs for itself (stream, pool, counters, live list, sort buffers, events).
-    int pipelines = -1;               // NORI_HIP_PIPELINES: 1 or 2; -1 = two for trees beyond the caches, one otherwise (measured, DESIGN finding 41)
+    int pipelines = -1;               // NORI_HIP_PIPELINES: 1 or 2; -1 = two for trees beyond the caches and for calls of at least twin_min_samples on scenes without
+                                      // images or subsurface shapes, one otherwise (measured, DESIGN findings 41 and 42)
+    unsigned long long twin_min_samples = 1ull << 20;   // NORI_HIP_TWIN_MIN (measured from 1 M samples per call on: cbox 512 x 512 x 4 spp 4.93 -> 4.81 ms, x 16 spp 10.0 -> 9.0)
+    // two pipelines on a scene that lives in the caches: the trace stage leaves a part of every CU to the other pipeline's shade stage, which then
+    // runs beside it instead of after it - three workgroups of 256 per CU instead of five, and the shade stage built for five waves per SIMD (it
+    // fits beside them twice).  Only where NORI_HIP_TRACE_BPC / NORI_HIP_SHADE_WAVES were not given.  Set per call by render_entry.
+    int twin_trace_bpc = 0, twin_shade_waves = 0; bool shade_waves_given = false;
     NoriHipContext *twin = nullptr; bool is_twin = false;
     bool twin_tail_merged = true;     // NORI_HIP_TWIN_TAIL=separate: each pipeline launches its own tail kernel
     hipEvent_t twin_go = nullptr, twin_done = nullptr;
@@ -1570,7 +1576,8 @@ static int create_impl(NoriHipContext *c, int device) {
     if (const char *e = getenv("NORI_HIP_PIPELINES")) { int v = atoi(e); if (v == 1 || v == 2) c->pipelines = v; }
     if (const char *e = getenv("NORI_HIP_TWIN_TAIL")) c->twin_tail_merged = std::string(e) != "separate";
     if (const char *e = getenv("NORI_HIP_FINISH_WAVES")) { int v = atoi(e); if (v == 3 || v == 4) c->finish_waves = v; }
-    if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->shade_waves = v; }
+    if (const char *e = getenv("NORI_HIP_SHADE_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) { c->shade_waves = v; c->shade_waves_given = true; } }
+    if (const char *e = getenv("NORI_HIP_TWIN_MIN")) { long long v = atoll(e); if (v >= 0) c->twin_min_samples = (unsigned long long) v; }
     if (const char *e = getenv("NORI_HIP_SHADE_BPC")) { int v = atoi(e); if (v >= 1 && v <= 64) c->shade_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_TRACE_BPC")) { int v = atoi(e); if (v >= 0 && v <= 64) c->trace_blocks_per_cu = v; }
     if (const char *e = getenv("NORI_HIP_MEGA_WAVES")) { int v = atoi(e); if (v == 3 || v == 4 || v == 5 || v == 6 || v == 8) c->mega_waves = v; }
@@ -2119,7 +2126,17 @@ static void twin_borrow(NoriHipContext *t, const NoriHipContext *c) {
 // twin's, so for the caller the call completes in stream order as it always did.
 static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, int spp_begin, int spp_end) {
     SCENECHK(ctx);
-    const int np = ctx->pipelines > 0 ? ctx->pipelines : (tree_beyond_caches(ctx) ? 2 : 1);
+    const bool big_tree = tree_beyond_caches(ctx);
+    int np = ctx->pipelines > 0 ? ctx->pipelines : (big_tree ? 2 : 1);
+    if (ctx->pipelines <= 0 && !big_tree && !ctx->ext && tiles_xyxy && n_tiles >= 1 && n_tiles <= ND_MAX_TILES && spp_end > spp_begin) {
+        // a scene that lives in the caches: two pipelines pay from a few million samples per call on (finding 42)
+        unsigned long long total = 0;
+        for (int k = 0; k < n_tiles; ++k) {
+            const long long w_ = (long long) tiles_xyxy[4 * k + 2] - tiles_xyxy[4 * k], h_ = (long long) tiles_xyxy[4 * k + 3] - tiles_xyxy[4 * k + 1];
+            if (w_ > 0 && h_ > 0) total += (unsigned long long) (w_ * h_) * (unsigned long long) (spp_end - spp_begin);
+        }
+        if (total >= ctx->twin_min_samples) np = 2;
+    }
     if (np < 2 || ctx->is_twin || !uses_stages(ctx) || spp_end - spp_begin < 2 || spp_begin < 0) return render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
     if (!ctx->twin) {
         NoriHipContext *t = new NoriHipContext();
@@ -2130,6 +2147,7 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
     }
     if (!ctx->twin_go) { HIPCHK(hipEventCreateWithFlags(&ctx->twin_go, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->twin_done, hipEventDisableTiming)); }
     NoriHipContext *t = ctx->twin;
+    ctx->twin_trace_bpc = big_tree ? 0 : 3; ctx->twin_shade_waves = (big_tree || ctx->ext) ? 0 : 5;
     twin_borrow(t, ctx);
     const int mid = spp_begin + (spp_end - spp_begin + 1) / 2;             // (unequal halves measured worse: 56 / 62 / 75 % here: +1 / +6 / +7 % per step)
     HIPCHK(hipEventRecord(ctx->twin_go, ctx->stream));                    // what the caller queued before this call (a film clear, say) comes first for both
@@ -2154,6 +2172,7 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
     }
     (void) hipEventRecord(ctx->ev1, ctx->stream);                         // render_ms covers both pipelines
     ctx->stats.pipelines = 2;
+    ctx->twin_trace_bpc = 0; ctx->twin_shade_waves = 0;
     ctx->trace_width = std::max(ctx->trace_width, t->trace_width); ctx->trace_node_bytes = std::max(ctx->trace_node_bytes, t->trace_node_bytes);
     if (rc1 != NORI_HIP_OK) return fail(rc1, err1);
     if (rc2 != NORI_HIP_OK) return fail(rc2, err2);
@@ -2274,6 +2293,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     const int trace_waves = wide8 ? ND_WIDE8_WAVES : wide ? ND_WIDE_WAVES : 6;            // waves per SIMD the kernel is built for
     const size_t trace_fixed = wide8 ? ctx->trace_lds_wide8 : wide ? ctx->trace_lds_wide : ctx->trace_lds;               // stacks + staged rays (origin, direction, reciprocal direction, slot)
     int trace_bpc = ctx->trace_blocks_per_cu;
+    if (trace_bpc == 0 && ctx->twin_trace_bpc > 0 && trace_nw == 4) trace_bpc = ctx->twin_trace_bpc;
     if (trace_bpc == 0) trace_bpc = std::max(1, std::min<int>((int) (trace_waves * 4 / trace_nw), (int) (163840 / trace_fixed)));
     const int trace_resident = std::min<int>(trace_bpc, std::max<int>(1, (int) (trace_waves * 4 / trace_nw)));     // more workgroups than that run in rounds
     const size_t trace_share = (std::min<size_t>(ctx->lds_bytes, (size_t) 163840 / (size_t) trace_resident)) & ~(size_t) 255;
@@ -2294,7 +2314,7 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     };
     size_grids(P);
     Pool pools[2] = {ctx->pool, ctx->pool_b}; int pi = 0;                      // the pool in use; P shrinks with every compaction
-    const int SW = ctx->shade_waves;
+    const int SW = (!ctx->shade_waves_given && ctx->twin_shade_waves > 0) ? ctx->twin_shade_waves : ctx->shade_waves;
     void (*shade_kern)(DevScene, Pool, unsigned int, RenderJob, float4 *, unsigned int *, WfCounters *, unsigned long long *, DevStats *, unsigned int *) =
         ctx->ext ? k_shade_ext : SW == 3 ? k_shade_w3 : SW == 4 ? k_shade_w4 : SW == 5 ? k_shade_w5 : SW == 6 ? k_shade_w6 : k_shade_w8;
     // the shade stage writes the sort keys itself where a variant for that exists (the default ones); otherwise k_ray_keys does
