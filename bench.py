@@ -24,6 +24,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before anything starts the HIP runtime: see nori_hip/__init__.py
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cuda-path-tracer_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -399,6 +400,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     st = ctx.stats()
+    kname_stage = ctx.trace_kernel_name()
+    bvh_build_s = hs.bvh_build_seconds()
+    # (the context goes before the next one comes: every context that renders as two pipelines holds two streams, and a process whose
+    # streams outnumber its hardware queues has some of them share one - INTEGRATION.md, "two pipelines")
+    hs.close()
 
     # second line of evidence in the same run: BASELINE's metric is quoted on "cbox and the 10 M-triangle scene", so the
     # cbox workload (host tree in the reference's order) is timed too, with the same partition, barriers and max over ranks;
@@ -426,6 +432,7 @@ def main():
         n2 = w2["width"] * w2["height"] * w2["spp"] * steps2 * (1 if tiles else world)
         secondary = [{"workload": w2["name"], "value": round(n2 / dt2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt2 / steps2 * 1e3, 3),
                       "steps": steps2, "warmup": 1, "spp_per_gpu": w2["spp"], "bvh": "host SAH (reference order)"}]
+        hs2.close()
         os.environ["NORI_HIP_BVH"] = bvh
     # The same workload once more with every emitter sample's shadow ray traced (NORI_HIP_CULL=0), as the reference does it: the
     # library drops the ray when the sample's term is exactly zero (same film bit for bit).  Reported beside the
@@ -495,7 +502,7 @@ def main():
             survey_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays
         else:
             alg_bytes = 32.0 * k_boxes + 40.0 * k_prims + 60.0 * k_rays          # per trace launch
-        kname = ctx.trace_kernel_name()
+        kname = kname_stage
     else:
         alg_bytes = (32.0 * st["boxes_tested"] + 40.0 * st["prims_tested"]) / args.steps + 60.0 * rays + 32.0 * samples_per_step
         kname = ("k_render_ext" if info_ss else "k_render_img") if info_ext else "k_render_w%s" % os.environ.get("NORI_HIP_MEGA_WAVES", "4")
@@ -524,7 +531,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if w["xml"] is None else "reference scene files (scenes/)",
         "config": {"workload": w["name"], "width": w["width"], "height": w["height"], "spp_per_gpu": spp, "triangles": info["prims"],
                    "partition": (("interleaved 32-row bands, one render call per rank" if tiles else "spp slices") + ", RCCL all-reduce of the fp32 film") if world > 1 else "single GPU",
-                   "scene_load_s": round(load_s, 2), "bvh_build_s": round(hs.bvh_build_seconds(), 3),
+                   "scene_load_s": round(load_s, 2), "bvh_build_s": round(bvh_build_s, 3),
                    "bvh": ("device-built, %.1f ms, %d nodes, depth %d" % (bi["build_ms"], bi["n_used"], bi["depth"])) if bvh == "device" else "host SAH (reference order), %d 64-byte nodes" % info["wide_nodes"]},
         "mrays_per_s": round(rays_job / dt / 1e6, 2),
         "rays_per_sample": round(rays / (samples_per_step if not tiles else max(1, samples_per_step // world)), 3),

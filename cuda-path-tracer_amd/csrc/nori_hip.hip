@@ -2143,10 +2143,16 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
         t->device = ctx->device; t->is_twin = true;
         const int rc = create_impl(t, ctx->device);
         if (rc != NORI_HIP_OK) { const std::string why = g_err; nori_hip_destroy(t); g_err = why; return rc; }
+        (void) hipStreamDestroy(t->stream); t->stream = nullptr;            // (the twin's stream lives for the duration of a call, see below)
         ctx->twin = t;
     }
     if (!ctx->twin_go) { HIPCHK(hipEventCreateWithFlags(&ctx->twin_go, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->twin_done, hipEventDisableTiming)); }
     NoriHipContext *t = ctx->twin;
+    // The second stream is made for the call and given back after it: a stream holds a place on one of the process's hardware queues
+    // (GPU_MAX_HW_QUEUES, 4 by default), the runtime puts a new stream on the least used one, and two pipelines on one queue run one
+    // after the other - a context that kept its second stream while idle made the next context's land on its partner's queue
+    // (scratch/s2_queues.py: cbox 23.4 ms per step alone, 30.3 as the second context of a process).
+    if (!t->stream) HIPCHK(hipStreamCreate(&t->stream));
     ctx->twin_trace_bpc = big_tree ? 0 : 3; ctx->twin_shade_waves = (big_tree || ctx->ext) ? 0 : 5;
     twin_borrow(t, ctx);
     const int mid = spp_begin + (spp_end - spp_begin + 1) / 2;             // (unequal halves measured worse: 56 / 62 / 75 % here: +1 / +6 / +7 % per step)
@@ -2173,6 +2179,7 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
     (void) hipEventRecord(ctx->ev1, ctx->stream);                         // render_ms covers both pipelines
     ctx->stats.pipelines = 2;
     ctx->twin_trace_bpc = 0; ctx->twin_shade_waves = 0;
+    (void) hipStreamDestroy(t->stream); t->stream = nullptr;                // (work still in flight on it completes; ctx->stream waits for it through twin_done)
     ctx->trace_width = std::max(ctx->trace_width, t->trace_width); ctx->trace_node_bytes = std::max(ctx->trace_node_bytes, t->trace_node_bytes);
     if (rc1 != NORI_HIP_OK) return fail(rc1, err1);
     if (rc2 != NORI_HIP_OK) return fail(rc2, err2);
@@ -2508,8 +2515,7 @@ int nori_hip_stats(NoriHipContext *ctx, NoriHipStats *out) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<DevStats> stripes(ND_STRIPES);
     HIPCHK(hipMemcpy(stripes.data(), ctx->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
-    if (ctx->twin) {                  // the second pipeline's counters and trace launches count with the first's
-        HIPCHK(hipStreamSynchronize(ctx->twin->stream));
+    if (ctx->twin) {                  // the second pipeline's counters and trace launches count with the first's (its work is behind ctx->stream's)
         stripes.resize(2 * ND_STRIPES);
         HIPCHK(hipMemcpy(stripes.data() + ND_STRIPES, ctx->twin->d_stats, ND_STRIPES * sizeof(DevStats), hipMemcpyDeviceToHost));
     }
@@ -2544,7 +2550,7 @@ int nori_hip_reset_stats(NoriHipContext *ctx) {
     HIPCHK(hipMemsetAsync(ctx->d_stats, 0, ND_STRIPES * sizeof(DevStats), ctx->stream));
     ctx->fold_ext_events(); ctx->ext_ms_acc = 0.0; ctx->ext_launches = 0;
     if (ctx->twin) {
-        HIPCHK(hipMemsetAsync(ctx->twin->d_stats, 0, ND_STRIPES * sizeof(DevStats), ctx->twin->stream));
+        HIPCHK(hipMemsetAsync(ctx->twin->d_stats, 0, ND_STRIPES * sizeof(DevStats), ctx->stream));
         ctx->twin->fold_ext_events(); ctx->twin->ext_ms_acc = 0.0; ctx->twin->ext_launches = 0;
     }
     return NORI_HIP_OK;

@@ -10,6 +10,11 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# A render call may run as two pipelines on two streams, which only run side by side on two hardware queues; the HIP runtime gives a
+# process GPU_MAX_HW_QUEUES of them per device (4 unless set) and lets further streams share.  The library takes its second stream for
+# the duration of a call only (csrc/nori_hip.hip, render_entry), so that idle contexts do not hold places; a process that keeps many
+# streams busy at once wants more queues, and says so before the runtime starts (the variable is read once).  Unset: eight.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 class NoriHipError(RuntimeError):
