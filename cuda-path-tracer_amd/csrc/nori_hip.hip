@@ -2129,7 +2129,7 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
     const bool big_tree = tree_beyond_caches(ctx);
     int np = ctx->pipelines > 0 ? ctx->pipelines : (big_tree ? 2 : 1);
     if (ctx->pipelines <= 0 && !big_tree && !ctx->ext && tiles_xyxy && n_tiles >= 1 && n_tiles <= ND_MAX_TILES && spp_end > spp_begin) {
-        // a scene that lives in the caches: two pipelines pay from a few million samples per call on (finding 42)
+        // a scene that lives in the caches: two pipelines pay from about a million samples per call on (finding 42)
         unsigned long long total = 0;
         for (int k = 0; k < n_tiles; ++k) {
             const long long w_ = (long long) tiles_xyxy[4 * k + 2] - tiles_xyxy[4 * k], h_ = (long long) tiles_xyxy[4 * k + 3] - tiles_xyxy[4 * k + 1];
@@ -2153,20 +2153,23 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
     // after the other - a context that kept its second stream while idle made the next context's land on its partner's queue
     // (scratch/s2_queues.py: cbox 23.4 ms per step alone, 30.3 as the second context of a process).
     if (!t->stream) HIPCHK(hipStreamCreate(&t->stream));
+    HIPCHK(hipEventRecord(ctx->twin_go, ctx->stream));                    // what the caller queued before this call (a film clear, say) comes first for both
+    HIPCHK(hipStreamWaitEvent(t->stream, ctx->twin_go, 0));
+    // (no early return from here to the end: the per-call settings below are taken back and the second stream is given back on every path)
     ctx->twin_trace_bpc = big_tree ? 0 : 3; ctx->twin_shade_waves = (big_tree || ctx->ext) ? 0 : 5;
     twin_borrow(t, ctx);
     const int mid = spp_begin + (spp_end - spp_begin + 1) / 2;             // (unequal halves measured worse: 56 / 62 / 75 % here: +1 / +6 / +7 % per step)
-    HIPCHK(hipEventRecord(ctx->twin_go, ctx->stream));                    // what the caller queued before this call (a film clear, say) comes first for both
-    HIPCHK(hipStreamWaitEvent(t->stream, ctx->twin_go, 0));
     // The two pipelines reach their tails within a millisecond of each other.  Two tail kernels side by side get in each other's way (48 and
     // 65 ms where one launch over all the paths takes 48): each pipeline hands its live list back instead, and ONE launch finishes both.
     const bool merged_tail = ctx->twin_tail_merged;
     TailHandoff h1, h2;
     int rc2 = NORI_HIP_OK; std::string err2;
-    std::thread th([&]() { rc2 = render_impl(t, tiles_xyxy, n_tiles, mid, spp_end, merged_tail ? &h2 : nullptr); if (rc2 != NORI_HIP_OK) err2 = g_err; });
+    auto second = [&]() { rc2 = render_impl(t, tiles_xyxy, n_tiles, mid, spp_end, merged_tail ? &h2 : nullptr); if (rc2 != NORI_HIP_OK) err2 = g_err; };
+    std::thread th; bool threaded = true;
+    try { th = std::thread(second); } catch (...) { threaded = false; }     // (no thread to be had: the halves are queued one after the other, from this one)
     int rc1 = render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, mid, merged_tail ? &h1 : nullptr);
     std::string err1 = rc1 != NORI_HIP_OK ? g_err : std::string();
-    th.join();
+    if (threaded) th.join(); else second();
     (void) hipSetDevice(ctx->device);
     if (hipEventRecord(ctx->twin_done, t->stream) == hipSuccess) (void) hipStreamWaitEvent(ctx->stream, ctx->twin_done, 0);
     else { (void) hipGetLastError(); (void) hipStreamSynchronize(t->stream); }
