@@ -29,6 +29,27 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(L, n), n
 
 
+def test_binding_structs_have_the_sizes_of_the_header(tmp_path):
+    """The ctypes structures and numpy record types of nori_hip/__init__.py against sizeof() of the C structs they mirror, as a C
+    compiler sees include/nori_hip.h (a field added on one side only - NoriHipStats.pipelines in round 3 - would shift every later one)."""
+    import ctypes as C
+    import subprocess
+    pairs = [("NoriHipNode", NH.NODE_DTYPE.itemsize), ("NoriHipPrim", NH.PRIM_DTYPE.itemsize), ("NoriHipShadePrim", NH.SHADE_DTYPE.itemsize),
+             ("NoriHipShape", NH.SHAPE_DTYPE.itemsize), ("NoriHipTexture", NH.TEXTURE_DTYPE.itemsize), ("NoriHipEmitter", NH.EMITTER_DTYPE.itemsize),
+             ("NoriHipCamera", C.sizeof(NH.Camera)), ("NoriHipEnvMap", C.sizeof(NH.EnvMap)), ("NoriHipSceneDesc", C.sizeof(NH.SceneDesc)),
+             ("NoriHipRay", NH.RAY_DTYPE.itemsize), ("NoriHipHit", NH.HIT_DTYPE.itemsize), ("NoriHipStats", C.sizeof(NH.Stats))]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "nori_hip.h"\nint main(void) {\n' +
+                   "".join('    printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, size in pairs:
+        assert int(got[name]) == size, (name, got[name], size)
+    # and the last field of the statistics sits where the header puts it
+    assert NH.Stats.pipelines.offset == C.sizeof(NH.Stats) - 8
+
+
 @pytest.mark.parametrize("xml", XMLS)
 def test_host_loader_and_bvh_equal_the_oracle(xml):
     path = os.path.join(SCENES, xml)
