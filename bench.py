@@ -523,8 +523,9 @@ def main():
     if st.get("pipelines", 1) == 2:
         roof_note += ("; the render call ran as TWO pipelines side by side (DESIGN.md 5, finding 41), each over half of the samples with a pool of its own: a trace launch covers half "
                       "the slots and shares the GPU with the other pipeline's shade stage, ray sort or trace launch while it runs, so its duration - and with it frac, which is "
-                      "per launch - is not what the kernel reaches alone (NORI_HIP_PIPELINES=1: one pipeline, frac 0.57 on this workload, 11 % more time per step); "
-                      "whole_step_frac = the algorithmic bytes of all trace launches of a step over the step's time")
+                      "per launch - is not what the kernel reaches alone (NORI_HIP_PIPELINES=1 runs one pipeline%s); "
+                      "whole_step_frac = the algorithmic bytes of all trace launches of a step over the step's time") % (
+                          ": frac 0.57 on this workload, 11 % more time per step, profiles/r03_c4_bench_one_pipeline.json" if args.workload == "c4" else "")
     out = {
         "metric": "Msamples/s (path_mis, whole node)", "value": round(total_samples / dt / 1e6, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
