@@ -2137,7 +2137,21 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
         }
         if (total >= ctx->twin_min_samples) np = 2;
     }
-    if (np < 2 || ctx->is_twin || !uses_stages(ctx) || spp_end - spp_begin < 2 || spp_begin < 0) return render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
+    if (np < 2 || ctx->is_twin || !uses_stages(ctx) || spp_end <= spp_begin || spp_begin < 0 || !tiles_xyxy || n_tiles < 1) return render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
+    // How the call is halved: by samples; a call of one sample per pixel (a progressive display) by pixels instead - the two halves of its
+    // tile list, or the upper and lower half of its one tile, cut at a multiple of the 8-pixel patches the work items are dealt in.
+    const bool by_spp = spp_end - spp_begin >= 2;
+    int row_tiles[8]; const int *tiles_1 = tiles_xyxy, *tiles_2 = tiles_xyxy; int n_1 = n_tiles, n_2 = n_tiles;
+    if (!by_spp) {
+        if (n_tiles >= 2) { n_1 = n_tiles / 2; n_2 = n_tiles - n_1; tiles_2 = tiles_xyxy + 4 * (size_t) n_1; }
+        else {
+            const int y0 = tiles_xyxy[1], y1 = tiles_xyxy[3], ym = y0 + ((((y1 - y0) / 2) + 7) & ~7);
+            if (y1 - y0 < 16 || ym >= y1) return render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, spp_end);
+            for (int k = 0; k < 4; ++k) row_tiles[k] = row_tiles[4 + k] = tiles_xyxy[k];
+            row_tiles[3] = ym; row_tiles[5] = ym;
+            tiles_1 = row_tiles; tiles_2 = row_tiles + 4; n_1 = n_2 = 1;
+        }
+    }
     if (!ctx->twin) {
         NoriHipContext *t = new NoriHipContext();
         t->device = ctx->device; t->is_twin = true;
@@ -2159,15 +2173,16 @@ static int render_entry(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles,
     ctx->twin_trace_bpc = big_tree ? 0 : 3; ctx->twin_shade_waves = (big_tree || ctx->ext) ? 0 : 5;
     twin_borrow(t, ctx);
     const int mid = spp_begin + (spp_end - spp_begin + 1) / 2;             // (unequal halves measured worse: 56 / 62 / 75 % here: +1 / +6 / +7 % per step)
+    const int b_1 = spp_begin, e_1 = by_spp ? mid : spp_end, b_2 = by_spp ? mid : spp_begin, e_2 = spp_end;
     // The two pipelines reach their tails within a millisecond of each other.  Two tail kernels side by side get in each other's way (48 and
     // 65 ms where one launch over all the paths takes 48): each pipeline hands its live list back instead, and ONE launch finishes both.
     const bool merged_tail = ctx->twin_tail_merged;
     TailHandoff h1, h2;
     int rc2 = NORI_HIP_OK; std::string err2;
-    auto second = [&]() { rc2 = render_impl(t, tiles_xyxy, n_tiles, mid, spp_end, merged_tail ? &h2 : nullptr); if (rc2 != NORI_HIP_OK) err2 = g_err; };
+    auto second = [&]() { rc2 = render_impl(t, tiles_2, n_2, b_2, e_2, merged_tail ? &h2 : nullptr); if (rc2 != NORI_HIP_OK) err2 = g_err; };
     std::thread th; bool threaded = true;
     try { th = std::thread(second); } catch (...) { threaded = false; }     // (no thread to be had: the halves are queued one after the other, from this one)
-    int rc1 = render_impl(ctx, tiles_xyxy, n_tiles, spp_begin, mid, merged_tail ? &h1 : nullptr);
+    int rc1 = render_impl(ctx, tiles_1, n_1, b_1, e_1, merged_tail ? &h1 : nullptr);
     std::string err1 = rc1 != NORI_HIP_OK ? g_err : std::string();
     if (threaded) th.join(); else second();
     (void) hipSetDevice(ctx->device);

@@ -290,7 +290,7 @@ int nori_hip_pcg32(NoriHipContext *ctx, uint64_t state, uint64_t seq, size_t n, 
  * Replaces the body of RenderThread::renderScene's pass loop: renderBlock + ImageBlock::put
  * (src/render.cpp:151-190, src/block.cpp:93-111).
  * Over a tree that does not fit the caches (or with NORI_HIP_PIPELINES=2) the call runs as two pipelines side by side: the second half
- * of the sample range goes through a second pool on a second stream, queued by a helper thread that lives for the duration of the call;
+ * of the sample range (of the pixels, when the range is one sample) goes through a second pool on a second stream, queued by a helper thread that lives for the duration of the call;
  * the context's stream waits for that stream, so whatever the caller queues behind the call (a film read, a filter pass) still sees the
  * whole result.  Same samples, same film; NoriHipStats.pipelines says what ran.  The second pool is allocated on first use and kept.
  * A call that returns an error may have added a part of its samples to the film (as a call that fails half-way always could): clear or

@@ -317,13 +317,23 @@ def test_two_pipelines_per_render_call(loaded):
         for k in ("camera_samples", "closest_rays", "shadow_rays", "shadow_rays_culled", "invalid_samples", "prims_tested"):
             assert s2[k] == s1[k], (k, s2[k], s1[k])
         assert s2["extend_launches"] > s1["extend_launches"]               # (both pipelines' trace launches are counted)
-    # accumulation over calls, a one-sample call in between, ragged tile lists
+    # accumulation over calls; a one-sample call in between is halved by pixels (upper and lower half of the tile); ragged tile lists
     c2.clear_film(); c2.render(0, 3); c2.render(3, 4)
-    assert c2.stats()["pipelines"] == 1
+    assert c2.stats()["pipelines"] == 2
     c2.render_tiles(4, 7, [(0, 0, 13, 9), (13, 0, W, 9), (0, 9, 50, H), (50, 9, W, 41), (50, 41, W, H)])
     f3 = c2.read_film()
     assert c2.stats()["pipelines"] == 2
     assert np.array_equal(f3[:, :, 3], f1[:, :, 3]) and np.allclose(f3, f1, rtol=1e-4, atol=1e-5)
+    # one sample per pixel over a tile list (halved by tiles), over a tile too low to halve (one pipeline), and sample by sample
+    c2.clear_film()
+    c2.render_tiles(0, 1, [(0, 0, 13, 9), (13, 0, W, 9), (0, 9, 50, H), (50, 9, W, 41), (50, 41, W, H)])
+    assert c2.stats()["pipelines"] == 2
+    c2.render(1, 2, tile=(0, 0, W, 12)); assert c2.stats()["pipelines"] == 1
+    c2.render(1, 2, tile=(0, 12, W, H)); assert c2.stats()["pipelines"] == 2
+    for s_ in range(2, 7):
+        c2.render(s_, s_ + 1)
+    f4 = c2.read_film()
+    assert np.array_equal(f4[:, :, 3], f1[:, :, 3]) and np.allclose(f4, f1, rtol=1e-4, atol=1e-5)
     # a new scene on the same context: the twin follows
     hs3 = NH.HostScene(os.path.join(SCENES, SCENE_XML["table"]), W, H, 4)
     hs2.close()
