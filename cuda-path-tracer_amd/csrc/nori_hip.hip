@@ -2305,7 +2305,11 @@ static int render_impl(NoriHipContext *ctx, const int *tiles_xyxy, int n_tiles, 
     hipLaunchKernelGGL(k_pool_init, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool, P, c);
     const int3 thr = make_int3(ctx->thr_box, ctx->thr_prim, ctx->thr_refill);
     // (trees beyond the caches: the tail kernel takes over a little earlier, 5/16 of the pool - C4 286 -> 283 ms)
-    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : big_tree ? P / 16 * 5 : P / 4, P);
+    // ... and never later than at a million live paths: a stage launch lasts as long as its longest rays however few slots it sweeps, so a small
+    // call (or a small rest of a large one) is better off in the tail kernel from the start - C4 at 1 / 2 / 4 spp per call 55.0 / 72.9 / 114.6 ->
+    // 39.3 / 60.7 / 103.1 ms, cbox 512 x 512 at 4 / 16 spp 4.80 / 8.97 -> 4.19 / 8.38, dragon at 4 spp 9.14 -> 8.49; the full workloads are
+    // unchanged (their fraction of the pool is above a million, or equal within noise: cbox at 64 spp 23.5 / 23.4)
+    const unsigned int finish_below = std::min<unsigned int>(ctx->finish_below ? ctx->finish_below : std::max<unsigned int>(big_tree ? P / 16 * 5 : P / 4, 1u << 20), P);
     // the trace stages give every wave a static share of the pool, so all their workgroups must be resident at once.
     // LDS of a workgroup: stacks + staging buffers of its waves, the rest of its share caches the top of the tree.
     const unsigned trace_threads = (unsigned) ctx->trace_threads, trace_nw = trace_threads / 64;
