@@ -480,8 +480,10 @@ __device__ __forceinline__ void shade_body(const DevScene &sc, const Pool &pool,
     const float4 no_ray = make_float4(0.f, 0.f, 0.f, -1.f);
     if (threadIdx.x == 0) { l_regen = 0u; l_keep = 0u; }
     __syncthreads();
-    for (unsigned int i0 = lo + wv * 64u; i0 < hi; i0 += 256u) {
-        const unsigned int slot = i0 + lane;
+    // (the trip count is the block's, not the wave's: a wave whose 64 slots lie past the end of the run makes an empty trip.  Written this way
+    // the EXT build of the stage allocates its registers better - cbox_subsurface 92.3 -> 89.5 ms per step on one box, the others unchanged)
+    for (unsigned int ib = lo; ib < hi; ib += 256u) {
+        const unsigned int slot = ib + threadIdx.x;
         bool regen = false, keep = false, idle = false;
         F3 kp = f3(0.f); bool kvalid = false;            // where the slot's path stands after this bounce (the ray sort's key), if it has a ray
         if (slot < hi) {
